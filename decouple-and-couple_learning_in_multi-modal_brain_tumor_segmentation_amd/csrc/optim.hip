@@ -1,0 +1,105 @@
+// K11/K12 + misc -- fused multi-tensor Adam(amsgrad), the batched weight-pack gather, and trivial elementwise
+// helpers.  Reference: torch.optim.Adam(lr=2e-4, weight_decay=1e-5, amsgrad=True) at train_no_amp.py:136,239
+// (L2 decay added to the gradient, max of second moments, bias corrections as in torch/optim/adam.py
+// _single_tensor_adam).  All HBM-bound.
+#include "common.h"
+
+__global__ void gather_batched_kernel(const cwf_gather_desc* __restrict__ table) {
+  const cwf_gather_desc d = table[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t m = d.map[i];
+    d.dst[i] = m >= 0 ? d.src[m] : 0.f;
+  }
+}
+
+extern "C" int cwf_gather_batched(const struct cwf_gather_desc* table, int nlayers, int64_t max_n, void* stream) {
+  if (!table || nlayers <= 0 || max_n <= 0) return CWF_E_BADARG;
+  int64_t gx = cdiv64(max_n, 256); if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(gather_batched_kernel, dim3((unsigned)gx, nlayers), dim3(256), 0, cwf_stream(stream), table);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void adam_kernel(const cwf_adam_desc* __restrict__ table, float lr, float beta1, float beta2, float eps, float wd,
+                            float bc1, float bc2_sqrt, int amsgrad) {
+  const cwf_adam_desc d = table[blockIdx.y];
+  const float step_size = lr / bc1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float p = d.p[i];
+    const float g = d.g[i] + wd * p;
+    const float m = d.m[i] + (1.f - beta1) * (g - d.m[i]);          // exp_avg.lerp_(grad, 1 - beta1)
+    const float v = beta2 * d.v[i] + (1.f - beta2) * g * g;         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    d.m[i] = m; d.v[i] = v;
+    float vv = v;
+    if (amsgrad) { vv = fmaxf(d.vmax[i], v); d.vmax[i] = vv; }
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    d.p[i] = p - step_size * (m / denom);
+  }
+}
+
+extern "C" int cwf_adam_amsgrad(const struct cwf_adam_desc* table, int ntensors, int64_t max_n,
+                                float lr, float beta1, float beta2, float eps, float weight_decay, int step, int amsgrad, void* stream) {
+  if (!table || ntensors <= 0 || max_n <= 0 || step <= 0) return CWF_E_BADARG;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = 1.f - powf(beta2, (float)step);
+  int64_t gx = cdiv64(max_n, 256); if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gx, ntensors), dim3(256), 0, cwf_stream(stream), table, lr, beta1, beta2, eps, weight_decay,
+                     bc1, sqrtf(bc2), amsgrad);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = a[i] * b[i];
+}
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = a[i] + b[i];
+}
+__global__ void channel_scale_kernel(const float* __restrict__ x, int x_ldc, const float* __restrict__ s, float* __restrict__ y, int y_ldc,
+                                     int64_t V, int C, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int CQ = C >> 2; const int cq = (int)(idx % CQ); const int64_t gv = idx / CQ; const int64_t n = gv / V;
+  const float4 sv = *reinterpret_cast<const float4*>(s + n * C + cq * 4);
+  float4 xv = *reinterpret_cast<const float4*>(x + gv * x_ldc + cq * 4);
+  xv.x *= sv.x; xv.y *= sv.y; xv.z *= sv.z; xv.w *= sv.w;
+  *reinterpret_cast<float4*>(y + gv * y_ldc + cq * 4) = xv;
+}
+__global__ void copy_strided_kernel(const float* __restrict__ x, int x_ldc, float* __restrict__ y, int y_ldc, int C, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int CQ = C >> 2; const int cq = (int)(idx % CQ); const int64_t gv = idx / CQ;
+  *reinterpret_cast<float4*>(y + gv * y_ldc + cq * 4) = *reinterpret_cast<const float4*>(x + gv * x_ldc + cq * 4);
+}
+
+extern "C" int cwf_mul(const float* a, const float* b, float* y, int64_t n, void* stream) {
+  if (!a || !b || !y || n <= 0) return CWF_E_BADARG;
+  hipLaunchKernelGGL(mul_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, cwf_stream(stream), a, b, y, n);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int cwf_add(const float* a, const float* b, float* y, int64_t n, void* stream) {
+  if (!a || !b || !y || n <= 0) return CWF_E_BADARG;
+  hipLaunchKernelGGL(add_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, cwf_stream(stream), a, b, y, n);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int cwf_channel_scale(const float* x, int x_ldc, const float* s, float* y, int y_ldc, int N, int64_t V, int C, void* stream) {
+  if (!x || !s || !y || N <= 0 || V <= 0 || (C & 3) || (x_ldc & 3) || (y_ldc & 3)) return CWF_E_BADARG;
+  const int64_t total = (int64_t)N * V * (C >> 2);
+  hipLaunchKernelGGL(channel_scale_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, cwf_stream(stream), x, x_ldc, s, y, y_ldc, V, C, total);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int cwf_copy_strided(const float* x, int x_ldc, float* y, int y_ldc, int64_t nvox, int C, void* stream) {
+  if (!x || !y || nvox <= 0 || (C & 3) || (x_ldc & 3) || (y_ldc & 3)) return CWF_E_BADARG;
+  const int64_t total = nvox * (C >> 2);
+  hipLaunchKernelGGL(copy_strided_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, cwf_stream(stream), x, x_ldc, y, y_ldc, C, total);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cwf_version(void) { return 1; }
+extern "C" const char* cwf_arch(void) { return "gfx950"; }

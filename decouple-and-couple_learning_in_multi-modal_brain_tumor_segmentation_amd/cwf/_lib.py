@@ -1,0 +1,90 @@
+"""ctypes binding of libcwf_hip.so (include/cwf_hip.h).  The product path has NO fallback: if the
+library is missing this raises, and every wrapper raises on a non-zero status."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcwf_hip.so")
+
+P = C.c_void_p
+I = C.c_int
+L = C.c_int64
+F = C.c_float
+U = C.c_uint32
+
+# name -> argtypes, exactly as declared in include/cwf_hip.h
+SIGNATURES = {
+    "cwf_version": [],
+    "cwf_conv_mfma": [I, P, I, P, P, P, I, P, P, F, P, I, P, P, I, I, I, I, I, I, I, I, I, P],
+    "cwf_wgrad_nsplit": [I, I, I, I, I, I, I],
+    "cwf_wgrad_partial_floats": [I, I, I, I, I, I, I],
+    "cwf_wgrad_slab_floats": [I, I, I],
+    "cwf_wgrad_mfma": [I, P, I, P, P, F, P, I, P, I, I, I, I, I, I, I, I, I, P],
+    "cwf_wgrad_reduce": [P, I, L, P, P, L, P, P, L, P],
+    "cwf_gather_batched": [P, I, L, P],
+    "cwf_in_finalize": [P, P, P, I, L, F, P],
+    "cwf_in_stats": [P, I, P, I, L, I, P],
+    "cwf_norm_act_add": [P, I, P, P, F, P, I, P, I, I, L, I, P],
+    "cwf_in_bwd_stats": [P, I, P, I, P, P, F, P, I, L, I, P],
+    "cwf_in_bwd_apply": [P, I, P, I, P, P, F, P, P, I, P, I, I, L, I, P],
+    "cwf_gemm": [P, L, L, L, L, P, L, L, L, L, P, L, L, L, P, P, L, L, L, I, I, I, I, I, F, I, I, P],
+    "cwf_layernorm_fwd": [P, P, P, P, P, P, I, I, F, P],
+    "cwf_layernorm_bwd": [P, P, P, P, P, P, P, P, I, I, I, P],
+    "cwf_softmax_rows": [P, L, I, I, P],
+    "cwf_softmax_rows_bwd": [P, P, L, I, I, P],
+    "cwf_gelu_bwd": [P, P, P, L, P],
+    "cwf_colsum": [P, L, I, I, P, I, P],
+    "cwf_window_to_tokens": [P, I, P, I, I, I, I, I, I, I, I, P],
+    "cwf_tokens_to_window": [P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "cwf_token_scores": [P, P, L, P, I, I, I, P],
+    "cwf_topk": [P, P, I, I, I, P],
+    "cwf_gather_tokens": [P, P, P, L, P, F, P, I, I, I, I, P],
+    "cwf_gather_tokens_bwd": [P, P, P, P, P, L, I, I, I, I, P],
+    "cwf_scatter_rows": [P, P, P, L, L, P, L, P, I, I, I, I, P],
+    "cwf_scatter_rows_bwd": [P, P, P, P, L, P, I, P, L, L, P, L, I, I, I, I, P],
+    "cwf_upsample_softmax": [P, I, P, I, I, I, I, I, I, P],
+    "cwf_upsample_softmax_bwd": [P, P, P, I, I, I, I, I, I, I, P],
+    "cwf_channel_softmax": [P, I, P, L, I, P],
+    "cwf_channel_softmax_bwd": [P, P, P, I, L, I, P],
+    "cwf_dice_ce_sums": [P, P, U, P, I, L, I, P],
+    "cwf_dice_ce_finalize": [P, P, P, I, L, I, P],
+    "cwf_dice_ce_bwd": [P, P, U, P, P, P, I, L, I, P],
+    "cwf_adam_amsgrad": [P, I, L, F, F, F, F, F, I, I, P],
+    "cwf_mul": [P, P, P, L, P],
+    "cwf_add": [P, P, P, L, P],
+    "cwf_channel_scale": [P, I, P, P, I, I, L, I, P],
+    "cwf_copy_strided": [P, I, P, I, L, I, P],
+}
+RESTYPE_INT64 = {"cwf_wgrad_partial_floats", "cwf_wgrad_slab_floats"}
+
+_lib = None
+
+
+class CwfError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the in-tree library and attach prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CwfError("libcwf_hip.so is not built (%s); run `python __graft_entry__.py` or `make -C csrc`. "
+                       "There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = L if name in RESTYPE_INT64 else I
+    lib.cwf_arch.restype = C.c_char_p
+    lib.cwf_arch.argtypes = []
+    _lib = lib
+    return lib
+
+
+def check(rc, name):
+    if rc != 0:
+        raise CwfError("%s failed with status %d" % (name, rc))

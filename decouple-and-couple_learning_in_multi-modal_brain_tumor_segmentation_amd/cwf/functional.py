@@ -1,0 +1,488 @@
+"""torch.autograd.Function glue over the HIP kernels (cwf/kernels.py).  Python only sequences launches and owns
+tensors; all arithmetic is in csrc/*.hip.  Activations are [N, D, H, W, C] (NDHWC), tokens [B, T, E].
+
+Fusion choices: InstanceNorm statistics of a conv OUTPUT come from that conv's epilogue; the
+normalise + (Leaky)ReLU of a conv INPUT is applied in the consumer's staging prologue, in forward, in the weight
+gradient (recomputed) and undone analytically in the data gradient (full InstanceNorm backward).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import packing as pk
+from .kernels import backend
+
+
+# ======================================================================================================
+# per-layer conv description + once-per-step weight packing
+# ======================================================================================================
+class ConvSpec:
+    """Static description of one conv layer: op code, channel counts and the index maps (device tensors)."""
+
+    def __init__(self, op, cin, cout):
+        self.op, self.cin, self.cout = op, cin, cout
+        self.cout_alloc = (cout + 3) // 4 * 4
+        self.np_fwd = pk.fwd_map(op, cin, cout)
+        self.np_dgrad = pk.dgrad_map(op, cin, cout, self.cout_alloc)
+        self.np_wmap, self.np_bmap, self.slab = pk.wgrad_maps(op, cin, cout)
+        self.dev = None
+        self.fwd_map = self.dgrad_map = self.w_map = self.b_map = None
+        self.wpk_f = self.wpk_d = None
+
+    def to(self, device):
+        if self.dev == device:
+            return self
+        t = lambda a: None if a is None else torch.from_numpy(a).to(device)
+        self.fwd_map, self.dgrad_map, self.w_map, self.b_map = t(self.np_fwd), t(self.np_dgrad), t(self.np_wmap), t(self.np_bmap)
+        self.wpk_f = torch.zeros(self.np_fwd.size, dtype=torch.float32, device=device)
+        self.wpk_d = torch.zeros(self.np_dgrad.size, dtype=torch.float32, device=device)
+        self.dev = device
+        return self
+
+
+class WeightPacker:
+    """Packs every conv weight into the MFMA B-operand layouts (forward + data-gradient forms) with ONE launch
+    per step (cwf_gather_batched over a device-resident descriptor table)."""
+
+    def __init__(self):
+        self.items = []          # (spec, weight Parameter)
+        self._key = None
+        self._table = None
+        self._max_n = 0
+
+    def add(self, spec, weight):
+        self.items.append((spec, weight))
+
+    def refresh(self):
+        if not self.items:
+            return
+        dev = self.items[0][1].device
+        key = (dev, tuple(w.data_ptr() for _, w in self.items))
+        if key != self._key:
+            rows = []
+            for spec, w in self.items:
+                spec.to(dev)
+                assert w.is_contiguous()
+                rows.append([w.data_ptr(), spec.wpk_f.data_ptr(), spec.fwd_map.data_ptr(), spec.fwd_map.numel()])
+                rows.append([w.data_ptr(), spec.wpk_d.data_ptr(), spec.dgrad_map.data_ptr(), spec.dgrad_map.numel()])
+            self._table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            self._max_n = max(r[3] for r in rows)
+            self._key = key
+        backend().gather_batched(self._table, self._table.shape[0], self._max_n)
+
+
+# ======================================================================================================
+# conv family
+# ======================================================================================================
+class _ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, spec, in_scale, in_shift, slope, residual, out_scale, want_stats):
+        K = backend()
+        n = x.shape[0]
+        stats = K.new_stats(n, spec.cout, x.device) if want_stats else None
+        y = K.conv(spec.op, x, spec.wpk_f, b, spec.cout, in_scale, in_shift, slope, residual, out_scale, stats,
+                   w_ref=w, out_channels_alloc=spec.cout_alloc)
+        ctx.spec, ctx.slope = spec, slope
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, w, in_scale, in_shift, out_scale)
+        if want_stats:
+            sc, sh = K.in_finalize(stats, y.shape[1] * y.shape[2] * y.shape[3])
+            ctx.mark_non_differentiable(sc, sh)
+            return y, sc, sh
+        return y, None, None
+
+    @staticmethod
+    def backward(ctx, dy, _a, _b):
+        K = backend()
+        x, w, in_scale, in_shift, out_scale = ctx.saved_tensors
+        spec = ctx.spec
+        if out_scale is not None:
+            dy = K.channel_scale(dy, out_scale)
+        dres = dy if ctx.has_res else None
+        dw = db = dx = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dyv = dy[..., :spec.cout] if dy.shape[-1] != spec.cout else dy
+            dwf, db = K.wgrad(spec.op, x, in_scale, in_shift, ctx.slope, dyv, spec.cout, spec.w_map, spec.b_map, w.numel(), w_ref_shape=w.shape)
+            dw = dwf.view(w.shape)
+            if db is None:      # ConvTranspose: bias gradient spans the 8 parity classes
+                db = K.in_stats(dy)[:, :, 0].sum(0).float()
+        if ctx.needs_input_grad[0]:
+            dxa = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            K.conv(pk.dgrad_op(spec.op), dy, spec.wpk_d, None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op)
+            if in_scale is not None:
+                dx = K.in_bwd(dxa, x, in_scale, in_shift, ctx.slope)
+            else:
+                dx = dxa
+        return dx, dw, db, None, None, None, None, dres, None, None
+
+
+def conv(x, w, b, spec, in_norm=None, slope=1.0, residual=None, out_scale=None, want_stats=False):
+    """y = conv(act(IN(x)))(+bias)(+residual)(*out_scale).  in_norm = (scale, shift) of x or None.
+    Returns (y, (scale_y, shift_y) or None)."""
+    sc, sh = in_norm if in_norm is not None else (None, None)
+    y, s1, s2 = _ConvFn.apply(x, w, b, spec, sc, sh, float(slope), residual, out_scale, want_stats)
+    return y, ((s1, s2) if want_stats else None)
+
+
+class _NormActAddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, shift, slope, residual):
+        ctx.slope = slope
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, scale, shift)
+        return backend().norm_act_add(x, scale, shift, slope, residual)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale, shift = ctx.saved_tensors
+        dx = backend().in_bwd(dy, x, scale, shift, ctx.slope)
+        return dx, None, None, None, (dy if ctx.has_res else None)
+
+
+def norm_act_add(x, stats, slope, residual=None):
+    return _NormActAddFn.apply(x, stats[0], stats[1], float(slope), residual)
+
+
+class _CatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        K = backend()
+        ca, cb = a.shape[-1], b.shape[-1]
+        out = torch.empty(a.shape[:-1] + (ca + cb,), dtype=torch.float32, device=a.device)
+        K.copy_into(a, out[..., :ca])
+        K.copy_into(b, out[..., ca:])
+        ctx.ca = ca
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return d[..., :ctx.ca], d[..., ctx.ca:]
+
+
+def cat_channels(a, b):
+    return _CatFn.apply(a, b)
+
+
+# ======================================================================================================
+# token path
+# ======================================================================================================
+class _WindowToTokensFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, patch):
+        ctx.patch, ctx.size, ctx.c = patch, tuple(x.shape[1:4]), x.shape[4]
+        return backend().window_to_tokens(x, patch)
+
+    @staticmethod
+    def backward(ctx, d):
+        return backend().tokens_to_window(d, ctx.size, ctx.c, ctx.patch), None
+
+
+class _TokensToWindowFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tok, size, channels, patch):
+        ctx.patch = patch
+        return backend().tokens_to_window(tok, size, channels, patch)
+
+    @staticmethod
+    def backward(ctx, d):
+        return backend().window_to_tokens(d, ctx.patch), None, None, None
+
+
+def window_to_tokens(x, patch):
+    return _WindowToTokensFn.apply(x, tuple(patch))
+
+
+def tokens_to_window(tok, size, channels, patch):
+    return _TokensToWindowFn.apply(tok, tuple(size), channels, tuple(patch))
+
+
+class _SelectFn(torch.autograd.Function):
+    """score = feats . score_tok ; top-k ; gather rows (+pe const, *keep) ; prepend head token.  (:345-350)"""
+
+    @staticmethod
+    def forward(ctx, feats, score_tok, head, k, keep, forced_index):
+        K = backend()
+        if forced_index is None:
+            score = K.token_scores(feats, score_tok)
+            index = K.topk(score, k)
+        else:
+            index = forced_index.to(torch.int32).contiguous()
+        seq = K.gather_tokens(feats, index, head, keep, 1.0)
+        ctx.save_for_backward(index, keep)
+        ctx.fshape, ctx.hshape = feats.shape, head.shape
+        ctx.mark_non_differentiable(index)
+        return seq, index
+
+    @staticmethod
+    def backward(ctx, dseq, _):
+        K = backend()
+        index, keep = ctx.saved_tensors
+        dfeats = torch.zeros(ctx.fshape, dtype=torch.float32, device=dseq.device) if ctx.needs_input_grad[0] else None
+        dhead = torch.zeros(ctx.hshape, dtype=torch.float32, device=dseq.device) if ctx.needs_input_grad[2] else None
+        K.gather_tokens_bwd(dseq, index, keep, dfeats, dhead)
+        return dfeats, None, dhead, None, None, None
+
+
+def select_tokens(feats, score_tok, head, k, keep=None, forced_index=None):
+    return _SelectFn.apply(feats, score_tok.detach(), head, k, keep, forced_index)
+
+
+class _ScatterGateFn(torch.autograd.Function):
+    """scat = feats with rows[index] replaced ; gated = scat * gate.  Returns (gated, scat).  (:463-485)"""
+
+    @staticmethod
+    def forward(ctx, feats, index, rows, gate):
+        K = backend()
+        scat = K.scatter_rows(feats, index, rows, None)
+        gated = K.scatter_rows(feats, index, rows, gate)
+        ctx.save_for_backward(index, scat, gate)
+        ctx.k = index.shape[1]
+        return gated, scat
+
+    @staticmethod
+    def backward(ctx, dgated, dscat):
+        K = backend()
+        index, scat, gate = ctx.saved_tensors
+        dfeats, drows, dgate = K.scatter_rows_bwd(dgated, index, scat, gate, ctx.k)
+        if dscat is not None:
+            df2, dr2, _ = K.scatter_rows_bwd(dscat, index, None, None, ctx.k)
+            dfeats, drows = K.add(dfeats, df2), K.add(drows, dr2)
+        return dfeats, None, drows, dgate
+
+
+def scatter_gate(feats, index, rows, gate):
+    return _ScatterGateFn.apply(feats, index, rows, gate)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        y, mean, rstd = backend().layernorm_fwd(x, gamma, beta)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dg = torch.zeros_like(gamma)
+        db = torch.zeros_like(gamma)
+        dx = backend().layernorm_bwd(dy, x.contiguous(), gamma, mean, rstd, dg, db)
+        return dx, dg, db
+
+
+def layer_norm(x, gamma, beta):
+    return _LayerNormFn.apply(x, gamma, beta)
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) + residual ; x [B,T,K], W [N,K] (any row-slice view with unit inner stride)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, residual):
+        K = backend()
+        x = x.contiguous()
+        bsz, t, kk = x.shape
+        n = w.shape[0]
+        assert w.stride(1) == 1
+        y = torch.empty((bsz, t, n), dtype=torch.float32, device=x.device)
+        res = residual.contiguous() if residual is not None else None
+        K.gemm(x, (kk, 1, 0, 0), w, (1, w.stride(0), 0, 0), y, (n, 0, 0), bsz * t, n, kk, bias=b, residual=res, sr=(n, 0, 0), act=act)
+        ctx.act, ctx.has_res, ctx.has_b = act, residual is not None, b is not None
+        ctx.save_for_backward(x, w, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        K = backend()
+        x, w, b = ctx.saved_tensors
+        dy = dy.contiguous()
+        bsz, t, kk = x.shape
+        n = w.shape[0]
+        m = bsz * t
+        dz = dy
+        if ctx.act:     # recompute the pre-activation (cheap) instead of storing it
+            z = torch.empty_like(dy)
+            K.gemm(x, (kk, 1, 0, 0), w, (1, w.stride(0), 0, 0), z, (n, 0, 0), m, n, kk, bias=b)
+            dz = K.gelu_bwd(z, dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            K.gemm(dz, (n, 1, 0, 0), w, (w.stride(0), 1, 0, 0), dx, (kk, 0, 0), m, kk, n)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((n, kk), dtype=torch.float32, device=x.device)
+            K.gemm(dz, (1, n, 0, 0), x, (kk, 1, 0, 0), dw, (kk, 0, 0), n, kk, m)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = K.colsum(dz.view(m, n))
+        return dx, dw, db, None, (dy if ctx.has_res else None)
+
+
+def linear(x, w, b=None, act=0, residual=None):
+    return _LinearFn.apply(x, w, b, act, residual)
+
+
+class _AttnCoreFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d)) v over `heads` heads; q [B,Tq,E], kv [B,Tk,2E] (k | v).  (SelfAttention.py:94-98)"""
+
+    @staticmethod
+    def forward(ctx, q, kv, heads, pmask):
+        K = backend()
+        q, kv = q.contiguous(), kv.contiguous()
+        b, tq, e = q.shape
+        tk = kv.shape[1]
+        hd = e // heads
+        p = torch.empty((b, heads, tq, tk), dtype=torch.float32, device=q.device)
+        K.gemm(q, (e, 1, tq * e, hd), kv, (1, 2 * e, tk * 2 * e, hd), p, (tk, heads * tq * tk, tq * tk), tq, tk, hd,
+               zb=b, zh=heads, alpha=hd ** -0.5)
+        K.softmax_rows_(p)
+        pd = K.mul(p, pmask) if pmask is not None else p
+        o = torch.empty((b, tq, e), dtype=torch.float32, device=q.device)
+        K.gemm(pd, (tk, 1, heads * tq * tk, tq * tk), kv, (2 * e, 1, tk * 2 * e, hd), o, (e, tq * e, hd), tq, hd, tk,
+               zb=b, zh=heads, b_off=e)
+        ctx.heads = heads
+        ctx.save_for_backward(q, kv, p, pmask)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        K = backend()
+        q, kv, p, pmask = ctx.saved_tensors
+        do = do.contiguous()
+        heads = ctx.heads
+        b, tq, e = q.shape
+        tk = kv.shape[1]
+        hd = e // heads
+        alpha = hd ** -0.5
+        sp = (tk, 1, heads * tq * tk, tq * tk)          # P as A(m=q,k=key)
+        spt = (1, tk, heads * tq * tk, tq * tk)         # P^T as A(m=key,k=q)
+        pd = K.mul(p, pmask) if pmask is not None else p
+        dkv = torch.empty_like(kv)
+        # dV[key][d] = sum_q Pd[q][key] dO[q][d]
+        K.gemm(pd, spt, do, (e, 1, tq * e, hd), dkv, (2 * e, tk * 2 * e, hd), tk, hd, tq, zb=b, zh=heads, c_off=e)
+        # dPd[q][key] = sum_d dO[q][d] V[key][d]
+        dp = torch.empty_like(p)
+        K.gemm(do, (e, 1, tq * e, hd), kv, (1, 2 * e, tk * 2 * e, hd), dp, (tk, heads * tq * tk, tq * tk), tq, tk, hd,
+               zb=b, zh=heads, b_off=e)
+        if pmask is not None:
+            dp = K.mul(dp, pmask)
+        K.softmax_rows_bwd_(p, dp)                       # dp <- dS
+        dq = torch.empty_like(q)
+        # dQ[q][d] = alpha sum_key dS[q][key] K[key][d]
+        K.gemm(dp, sp, kv, (2 * e, 1, tk * 2 * e, hd), dq, (e, tq * e, hd), tq, hd, tk, zb=b, zh=heads, alpha=alpha)
+        # dK[key][d] = alpha sum_q dS[q][key] Q[q][d]
+        K.gemm(dp, spt, q, (e, 1, tq * e, hd), dkv, (2 * e, tk * 2 * e, hd), tk, hd, tq, zb=b, zh=heads, alpha=alpha)
+        return dq, dkv, None, None
+
+
+def attention_core(q, kv, heads, pmask=None):
+    return _AttnCoreFn.apply(q, kv, heads, pmask)
+
+
+class _MulMaskFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        return backend().mul(x, mask)
+
+    @staticmethod
+    def backward(ctx, d):
+        (mask,) = ctx.saved_tensors
+        return backend().mul(d, mask), None
+
+
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return backend().add(a, b)
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d
+
+
+def add(a, b):
+    return _AddFn.apply(a, b)
+
+
+def dropout_mask(shape, p, device):
+    """Pre-scaled keep mask (torch's device RNG supplies the bits; the multiply is a HIP kernel)."""
+    return (torch.rand(shape, device=device) >= p).to(torch.float32) * (1.0 / (1.0 - p))
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.0:
+        return x
+    return _MulMaskFn.apply(x, dropout_mask(x.shape, p, x.device))
+
+
+# ======================================================================================================
+# heads and losses
+# ======================================================================================================
+class _UpsampleSoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logit, c, scale):
+        prob = backend().upsample_softmax(logit, c, scale)
+        ctx.c, ctx.scale, ctx.lo = c, scale, tuple(logit.shape)
+        ctx.save_for_backward(prob)
+        return prob
+
+    @staticmethod
+    def backward(ctx, dprob):
+        (prob,) = ctx.saved_tensors
+        n, d, h, w, ca = ctx.lo
+        return backend().upsample_softmax_bwd(dprob, prob, (n, d, h, w), ctx.c, ctx.scale, ca), None, None
+
+
+def upsample_softmax(logit, c, scale):
+    return _UpsampleSoftmaxFn.apply(logit, c, scale)
+
+
+class _ChannelSoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logit):
+        prob = backend().channel_softmax(logit, logit.shape[-1])
+        ctx.save_for_backward(prob)
+        return prob
+
+    @staticmethod
+    def backward(ctx, dprob):
+        (prob,) = ctx.saved_tensors
+        return backend().channel_softmax_bwd(dprob, prob)
+
+
+def channel_softmax(logit):
+    return _ChannelSoftmaxFn.apply(logit)
+
+
+class _DiceCeFn(torch.autograd.Function):
+    """dice_loss + softmax_weighted_loss of one probability map (tools.py:8-34)."""
+
+    @staticmethod
+    def forward(ctx, prob_cl, label, posmask):
+        loss, coef = backend().dice_ce(prob_cl, label, posmask)
+        ctx.posmask = posmask
+        ctx.save_for_backward(prob_cl, label, coef)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        prob_cl, label, coef = ctx.saved_tensors
+        gs = g.reshape(1).to(torch.float32).contiguous()
+        return backend().dice_ce_bwd(prob_cl, label, ctx.posmask, coef, gs), None, None
+
+
+def to_channels_last_view(prob_ncdhw):
+    """[N,C,D,H,W] (any strides) -> dense [N,D,H,W,C] tensor sharing memory when the input is already channels-last."""
+    t = prob_ncdhw.permute(0, 2, 3, 4, 1)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def dice_ce_loss(prob_ncdhw, label, posmask=0):
+    """prob [N,C,D,H,W] (C = 4: class = label; C = 2: class = (posmask >> label) & 1), label int64 [N,D,H,W]."""
+    label = label.contiguous()
+    if label.dtype != torch.int64:
+        label = label.long()
+    return _DiceCeFn.apply(to_channels_last_view(prob_ncdhw), label, int(posmask))

@@ -1,0 +1,375 @@
+"""Tensor-level wrappers over the C ABI (include/cwf_hip.h).  torch is used for device memory and the current
+stream only; every arithmetic op below is a launch of a hand-written gfx950 kernel.  There is no fallback:
+constructing HipBackend without the built library or without a GPU raises.
+
+Activation tensors are 5-D [N, D, H, W, C] with unit channel stride; a channel slice of a dense buffer is
+passed zero-copy as (data_ptr, ldc = stride(3)).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from . import packing as pk
+
+_f32 = torch.float32
+
+
+def cl(t: torch.Tensor):
+    """(tensor, ldc) of a channels-last activation usable by the kernels; copies only if the strides are unusable."""
+    assert t.dim() == 5 and t.dtype == _f32, (t.shape, t.dtype)
+    n, d, h, w, c = t.shape
+    s = t.stride()
+    ldc = s[3]
+    ok = s[4] == 1 and ldc >= c and ldc % 4 == 0 and s[2] == w * ldc and s[1] == h * w * ldc and s[0] == d * h * w * ldc \
+        and t.data_ptr() % 16 == 0
+    if not ok:
+        t = t.contiguous()
+        ldc = c
+        if c % 4:
+            raise ValueError("channel count must be a multiple of 4 for a copied activation")
+    return t, ldc
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.CwfError("no GPU visible: the cwf kernels are gfx950-only and there is no CPU fallback")
+        self._ws = {}
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def _call(self, name, *args):
+        rc = getattr(self.lib, name)(*args)
+        if rc != 0:
+            raise _lib.CwfError("%s failed with status %d" % (name, rc))
+
+    def workspace(self, key, nfloats, device):
+        """Grow-only scratch buffers (wgrad partial slabs).  Stream-ordered reuse is safe: one stream."""
+        buf = self._ws.get((key, device))
+        if buf is None or buf.numel() < nfloats:
+            buf = torch.empty(int(nfloats), dtype=_f32, device=device)
+            self._ws[(key, device)] = buf
+        return buf
+
+    # ------------------------------------------------------------------ K1
+    def conv(self, op, x, wpk, bias, cout, in_scale=None, in_shift=None, slope=1.0, residual=None, out_scale=None,
+             stats=None, out=None, w_ref=None, out_channels_alloc=None, fwd_op=None):
+        """Returns the output buffer.  With out_channels_alloc > cout the buffer has zero-filled padding channels
+        (2-channel heads live in 4-channel tensors so that every later kernel sees 16-byte voxel rows).
+        w_ref / fwd_op are ignored here (the test emulation uses them instead of the packed weights)."""
+        x, x_ldc = cl(x)
+        n, di, hi, wi, cin = x.shape
+        if op == pk.CONV3_S2_DGRAD or op == pk.CONVT2_DGRAD:
+            assert out is not None, "dgrad ops need an explicit output (its extent is not implied)"
+        if out is None:
+            do, ho, wo = pk.out_dims(op, di, hi, wi)
+            ca = out_channels_alloc or cout
+            buf = torch.zeros if ca != cout else torch.empty
+            out = buf((n, do, ho, wo, ca), dtype=_f32, device=x.device)
+        y = out
+        _, do, ho, wo, _ = y.shape
+        y_ldc = y.stride(3)
+        r_ldc = 0
+        if residual is not None:
+            residual, r_ldc = cl(residual)
+        self._call("cwf_conv_mfma", op, x.data_ptr(), x_ldc, wpk.data_ptr(), _p(bias), y.data_ptr(), y_ldc,
+                   _p(in_scale), _p(in_shift), float(slope), _p(residual), r_ldc, _p(out_scale), _p(stats),
+                   n, di, hi, wi, cin, do, ho, wo, cout, self._stream())
+        return y
+
+    def wgrad(self, op, x, in_scale, in_shift, slope, dy, cout, w_map, b_map, w_numel, w_ref_shape=None):
+        """returns (dW flat [w_numel], db [cout] or None)"""
+        x, x_ldc = cl(x)
+        dy, dy_ldc = cl(dy) if dy.shape[-1] % 4 == 0 or dy.stride(3) % 4 == 0 else (dy, dy.stride(3))
+        n, di, hi, wi, cin = x.shape
+        _, do, ho, wo, _ = dy.shape
+        nsplit = self.lib.cwf_wgrad_nsplit(op, n, do, ho, wo, cin, cout)
+        slab = self.lib.cwf_wgrad_slab_floats(op, cin, cout)
+        if nsplit <= 0 or slab <= 0:
+            raise _lib.CwfError("cwf_wgrad plan failed (%d, %d)" % (nsplit, slab))
+        part = self.workspace("wgrad", nsplit * slab, x.device)
+        self._call("cwf_wgrad_mfma", op, x.data_ptr(), x_ldc, _p(in_scale), _p(in_shift), float(slope),
+                   dy.data_ptr(), dy_ldc, part.data_ptr(), n, di, hi, wi, cin, do, ho, wo, cout, self._stream())
+        dw = torch.empty(w_numel, dtype=_f32, device=x.device)
+        db = torch.empty(cout, dtype=_f32, device=x.device) if b_map is not None else None
+        self._call("cwf_wgrad_reduce", part.data_ptr(), nsplit, slab, w_map.data_ptr(), dw.data_ptr(), w_numel,
+                   _p(b_map), _p(db), cout if b_map is not None else 0, self._stream())
+        return dw, db
+
+    def gather_batched(self, table, nlayers, max_n):
+        self._call("cwf_gather_batched", table.data_ptr(), nlayers, max_n, self._stream())
+
+    # ------------------------------------------------------------------ K3
+    def new_stats(self, n, c, device):
+        return torch.zeros((n, c, 2), dtype=torch.float64, device=device)
+
+    def in_finalize(self, stats, nvox, eps=1e-5):
+        n, c, _ = stats.shape
+        scale = torch.empty((n, c), dtype=_f32, device=stats.device)
+        shift = torch.empty((n, c), dtype=_f32, device=stats.device)
+        self._call("cwf_in_finalize", stats.data_ptr(), scale.data_ptr(), shift.data_ptr(), n * c, nvox, eps, self._stream())
+        return scale, shift
+
+    def in_stats(self, x):
+        x, ldc = cl(x)
+        n, d, h, w, c = x.shape
+        stats = self.new_stats(n, c, x.device)
+        self._call("cwf_in_stats", x.data_ptr(), ldc, stats.data_ptr(), n, d * h * w, c, self._stream())
+        return stats
+
+    def norm_act_add(self, x, scale, shift, slope, residual=None):
+        x, ldc = cl(x)
+        n, d, h, w, c = x.shape
+        y = torch.empty((n, d, h, w, c), dtype=_f32, device=x.device)
+        r_ldc = 0
+        if residual is not None:
+            residual, r_ldc = cl(residual)
+        self._call("cwf_norm_act_add", x.data_ptr(), ldc, scale.data_ptr(), shift.data_ptr(), float(slope), _p(residual), r_ldc,
+                   y.data_ptr(), c, n, d * h * w, c, self._stream())
+        return y
+
+    def in_bwd(self, dy, x, scale, shift, slope, dx_add=None):
+        """dx for y = act(IN(x)) given dy = dL/dy (full InstanceNorm backward, statistics included)."""
+        dy, dy_ldc = cl(dy)
+        x, x_ldc = cl(x)
+        n, d, h, w, c = x.shape
+        v = d * h * w
+        sums = self.new_stats(n, c, x.device)
+        self._call("cwf_in_bwd_stats", dy.data_ptr(), dy_ldc, x.data_ptr(), x_ldc, scale.data_ptr(), shift.data_ptr(), float(slope),
+                   sums.data_ptr(), n, v, c, self._stream())
+        dx = torch.empty((n, d, h, w, c), dtype=_f32, device=x.device)
+        a_ldc = 0
+        if dx_add is not None:
+            dx_add, a_ldc = cl(dx_add)
+        self._call("cwf_in_bwd_apply", dy.data_ptr(), dy_ldc, x.data_ptr(), x_ldc, scale.data_ptr(), shift.data_ptr(), float(slope),
+                   sums.data_ptr(), _p(dx_add), a_ldc, dx.data_ptr(), c, n, v, c, self._stream())
+        return dx
+
+    # ------------------------------------------------------------------ K6/K7
+    def gemm(self, a, sa, b, sb, c, sc, m, n, k, zb=1, zh=1, bias=None, residual=None, sr=(0, 0, 0), alpha=1.0, act=0,
+             accumulate=False, a_off=0, b_off=0, c_off=0, r_off=0):
+        """sa = (m, k, zb, zh) element strides of A; sb = (k, n, zb, zh); sc = (m, zb, zh); offsets in elements."""
+        self._call("cwf_gemm", a.data_ptr() + 4 * a_off, sa[0], sa[1], sa[2], sa[3],
+                   b.data_ptr() + 4 * b_off, sb[0], sb[1], sb[2], sb[3],
+                   c.data_ptr() + 4 * c_off, sc[0], sc[1], sc[2],
+                   _p(bias), (residual.data_ptr() + 4 * r_off) if residual is not None else 0, sr[0], sr[1], sr[2],
+                   m, n, k, zb, zh, float(alpha), act, int(accumulate), self._stream())
+        return c
+
+    def layernorm_fwd(self, x, gamma, beta, eps=1e-5):
+        rows, e = x.numel() // x.shape[-1], x.shape[-1]
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=_f32, device=x.device)
+        rstd = torch.empty(rows, dtype=_f32, device=x.device)
+        self._call("cwf_layernorm_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                   rows, e, eps, self._stream())
+        return y, mean, rstd
+
+    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dgamma, dbeta):
+        rows, e = x.numel() // x.shape[-1], x.shape[-1]
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        self._call("cwf_layernorm_bwd", dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                   dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, e, 0, self._stream())
+        return dx
+
+    def softmax_rows_(self, s):
+        cols = s.shape[-1]
+        self._call("cwf_softmax_rows", s.data_ptr(), s.numel() // cols, cols, cols, self._stream())
+        return s
+
+    def softmax_rows_bwd_(self, p, dp):
+        cols = p.shape[-1]
+        self._call("cwf_softmax_rows_bwd", p.data_ptr(), dp.data_ptr(), p.numel() // cols, cols, cols, self._stream())
+        return dp
+
+    def gelu_bwd(self, x, dy):
+        dx = torch.empty_like(x)
+        self._call("cwf_gelu_bwd", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), self._stream())
+        return dx
+
+    def colsum(self, x2d):
+        rows, cols = x2d.shape
+        out = torch.empty(cols, dtype=_f32, device=x2d.device)
+        self._call("cwf_colsum", x2d.data_ptr(), rows, cols, x2d.stride(0), out.data_ptr(), 0, self._stream())
+        return out
+
+    # ------------------------------------------------------------------ K4/K5
+    def window_to_tokens(self, x, patch):
+        x, ldc = cl(x)
+        b, d, h, w, c = x.shape
+        p0, p1, p2 = patch
+        tok = torch.empty((b, (d // p0) * (h // p1) * (w // p2), c * p0 * p1 * p2), dtype=_f32, device=x.device)
+        self._call("cwf_window_to_tokens", x.data_ptr(), ldc, tok.data_ptr(), b, d, h, w, c, p0, p1, p2, self._stream())
+        return tok
+
+    def tokens_to_window(self, tok, size, channels, patch):
+        b = tok.shape[0]
+        d, h, w = size
+        p0, p1, p2 = patch
+        tok = tok.contiguous()
+        x = torch.empty((b, d, h, w, channels), dtype=_f32, device=tok.device)
+        self._call("cwf_tokens_to_window", tok.data_ptr(), x.data_ptr(), channels, b, d, h, w, channels, p0, p1, p2, 0, self._stream())
+        return x
+
+    def token_scores(self, feats, query):
+        """feats [B,T,E]; query [1,1,E] (shared) or [B,1,E]."""
+        b, t, e = feats.shape
+        score = torch.empty((b, t), dtype=_f32, device=feats.device)
+        qbs = 0 if query.shape[0] == 1 else e
+        self._call("cwf_token_scores", feats.data_ptr(), query.data_ptr(), qbs, score.data_ptr(), b, t, e, self._stream())
+        return score
+
+    def topk(self, score, k):
+        b, t = score.shape
+        idx = torch.empty((b, k), dtype=torch.int32, device=score.device)
+        self._call("cwf_topk", score.data_ptr(), idx.data_ptr(), b, t, k, self._stream())
+        return idx
+
+    def gather_tokens(self, feats, index, head, keep=None, pe_odd=1.0):
+        b, t, e = feats.shape
+        k = index.shape[1]
+        seq = torch.empty((b, k + 1, e), dtype=_f32, device=feats.device)
+        hbs = 0 if head.shape[0] == 1 else e
+        self._call("cwf_gather_tokens", feats.data_ptr(), index.data_ptr(), head.data_ptr(), hbs, _p(keep), float(pe_odd),
+                   seq.data_ptr(), b, t, k, e, self._stream())
+        return seq
+
+    def gather_tokens_bwd(self, dseq, index, keep, dfeats, dhead):
+        """dfeats [B,T,E] accumulated in place (may be None); dhead [1 or B,1,E] accumulated in place (may be None)."""
+        b, k1, e = dseq.shape
+        dseq = dseq.contiguous()
+        t = dfeats.shape[1] if dfeats is not None else 0
+        dhbs = 0 if (dhead is None or dhead.shape[0] == 1) else e
+        self._call("cwf_gather_tokens_bwd", dseq.data_ptr(), index.data_ptr(), _p(keep), _p(dfeats), _p(dhead), dhbs,
+                   b, t, k1 - 1, e, self._stream())
+
+    def scatter_rows(self, feats, index, rows, gate=None):
+        """rows: [B,k,E] view (row stride / batch stride taken from the tensor); gate [B,1,E] view or None."""
+        b, t, e = feats.shape
+        k = index.shape[1]
+        assert rows.stride(2) == 1
+        out = torch.empty((b, t, e), dtype=_f32, device=feats.device)
+        gbs = gate.stride(0) if gate is not None else 0
+        self._call("cwf_scatter_rows", feats.data_ptr(), index.data_ptr(), rows.data_ptr(), rows.stride(1), rows.stride(0),
+                   _p(gate), gbs, out.data_ptr(), b, t, k, e, self._stream())
+        return out
+
+    def scatter_rows_bwd(self, dout, index, scat, gate, k, need_feats=True, need_rows=True):
+        """returns (dfeats [B,T,E] or None, drows [B,k,E] or None, dgate [B,1,E] or None)"""
+        b, t, e = dout.shape
+        dout = dout.contiguous()
+        dfeats = torch.empty((b, t, e), dtype=_f32, device=dout.device) if need_feats else None
+        drows = torch.empty((b, k, e), dtype=_f32, device=dout.device) if need_rows else None
+        dgate = torch.zeros((b, 1, e), dtype=_f32, device=dout.device) if gate is not None else None
+        gbs = gate.stride(0) if gate is not None else 0
+        self._call("cwf_scatter_rows_bwd", dout.data_ptr(), index.data_ptr(), _p(scat), _p(gate), gbs,
+                   _p(dfeats), 0, _p(drows), e, k * e, _p(dgate), e, b, t, k, e, self._stream())
+        return dfeats, drows, dgate
+
+    # ------------------------------------------------------------------ K8/K10
+    def upsample_softmax(self, logit, c, scale):
+        """logit [N,d,h,w,>=c] (channel stride from the tensor) -> prob [N,d*s,h*s,w*s,c]"""
+        n, d, h, w, _ = logit.shape
+        prob = torch.empty((n, d * scale, h * scale, w * scale, c), dtype=_f32, device=logit.device)
+        self._call("cwf_upsample_softmax", logit.data_ptr(), logit.stride(3), prob.data_ptr(), n, d, h, w, c, scale, self._stream())
+        return prob
+
+    def upsample_softmax_bwd(self, dprob, prob, lo_shape, c, scale, ldc_out):
+        n, d, h, w = lo_shape
+        dprob = dprob.contiguous()
+        dl = torch.zeros((n, d, h, w, ldc_out), dtype=_f32, device=prob.device)
+        self._call("cwf_upsample_softmax_bwd", dprob.data_ptr(), prob.data_ptr(), dl.data_ptr(), ldc_out, n, d, h, w, c, scale, self._stream())
+        return dl
+
+    def channel_softmax(self, logit, c):
+        n, d, h, w, _ = logit.shape
+        prob = torch.empty((n, d, h, w, c), dtype=_f32, device=logit.device)
+        self._call("cwf_channel_softmax", logit.data_ptr(), logit.stride(3), prob.data_ptr(), n * d * h * w, c, self._stream())
+        return prob
+
+    def channel_softmax_bwd(self, dprob, prob):
+        dprob = dprob.contiguous()
+        n, d, h, w, c = prob.shape
+        dl = torch.empty_like(prob)
+        self._call("cwf_channel_softmax_bwd", dprob.data_ptr(), prob.data_ptr(), dl.data_ptr(), c, n * d * h * w, c, self._stream())
+        return dl
+
+    # ------------------------------------------------------------------ K9
+    def dice_ce(self, prob, label, posmask):
+        """prob [N,D,H,W,C] dense channels-last, label int64 [N,D,H,W] -> (loss [1], coef [N,C,4])"""
+        n, d, h, w, c = prob.shape
+        v = d * h * w
+        sums = torch.zeros((n, c, 4), dtype=torch.float64, device=prob.device)
+        self._call("cwf_dice_ce_sums", prob.data_ptr(), label.data_ptr(), posmask, sums.data_ptr(), n, v, c, self._stream())
+        loss = torch.empty(1, dtype=_f32, device=prob.device)
+        coef = torch.empty((n, c, 4), dtype=_f32, device=prob.device)
+        self._call("cwf_dice_ce_finalize", sums.data_ptr(), loss.data_ptr(), coef.data_ptr(), n, v, c, self._stream())
+        return loss, coef
+
+    def dice_ce_bwd(self, prob, label, posmask, coef, gscale):
+        n, d, h, w, c = prob.shape
+        dprob = torch.empty_like(prob)
+        self._call("cwf_dice_ce_bwd", prob.data_ptr(), label.data_ptr(), posmask, coef.data_ptr(), gscale.data_ptr(), dprob.data_ptr(),
+                   n, d * h * w, c, self._stream())
+        return dprob
+
+    # ------------------------------------------------------------------ K11 / misc
+    def adam(self, table, ntensors, max_n, lr, beta1, beta2, eps, wd, step, amsgrad):
+        self._call("cwf_adam_amsgrad", table.data_ptr(), ntensors, max_n, lr, beta1, beta2, eps, wd, step, int(amsgrad), self._stream())
+
+    def mul(self, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        y = torch.empty_like(a)
+        self._call("cwf_mul", a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), self._stream())
+        return y
+
+    def add(self, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        y = torch.empty_like(a)
+        self._call("cwf_add", a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), self._stream())
+        return y
+
+    def channel_scale(self, x, s):
+        x, ldc = cl(x)
+        n, d, h, w, c = x.shape
+        y = torch.empty((n, d, h, w, c), dtype=_f32, device=x.device)
+        self._call("cwf_channel_scale", x.data_ptr(), ldc, s.data_ptr(), y.data_ptr(), c, n, d * h * w, c, self._stream())
+        return y
+
+    def copy_into(self, x, out):
+        """out[..., :] = x for channels-last views (zero-copy concat helper)."""
+        x, ldc = cl(x)
+        n, d, h, w, c = x.shape
+        self._call("cwf_copy_strided", x.data_ptr(), ldc, out.data_ptr(), out.stride(3), n * d * h * w, c, self._stream())
+        return out
+
+
+_backend = None
+
+
+def backend():
+    """The kernel backend of the product path: always the HIP library."""
+    global _backend
+    if _backend is None:
+        _backend = HipBackend()
+    return _backend
+
+
+def _set_backend_for_testing(obj):
+    """TEST-ONLY hook (tests/ inject oracle/kernel_emul.py to exercise the host-side autograd wiring on CPU).
+    Nothing in the package calls this."""
+    global _backend
+    _backend = obj

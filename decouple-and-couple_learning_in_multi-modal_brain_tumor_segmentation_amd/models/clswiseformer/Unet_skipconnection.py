@@ -1,0 +1,83 @@
+"""U-Net encoder of ClsWiseFormer on the HIP conv kernels (reference Unet_skipconnection.py:22-144).
+
+Same module tree / parameter names as the reference (InitConv.conv, EnBlock*.conv1/conv2, EnDown*.conv,
+EnDown_4.conv).  InstanceNorm + ReLU never run as separate passes: a conv's epilogue emits the statistics of its
+output and the consumer applies normalise + ReLU while staging its input tile (cwf_conv_mfma prologue).
+All activations are [N, D, H, W, C]."""
+import torch
+import torch.nn as nn
+
+from .layers import HipConv
+
+
+class InitConv(nn.Module):
+    """conv 4->16 followed by the reference's ALWAYS-ON channel dropout (F.dropout3d without a training flag,
+    Unet_skipconnection.py:29-33).  ``dropout`` may be set to 0.0 for deterministic runs."""
+
+    def __init__(self, in_channels=4, out_channels=16, dropout=0.2):
+        super().__init__()
+        self.conv = HipConv(in_channels, out_channels)
+        self.dropout = dropout
+
+    def forward(self, x, keep=None):
+        if keep is None and self.dropout > 0.0:
+            p = self.dropout
+            keep = (torch.rand((x.shape[0], self.conv.spec.cout), device=x.device) >= p).float() * (1.0 / (1.0 - p))
+        return self.conv(x, out_scale=keep, want_stats=True)
+
+
+class EnBlock(nn.Module):
+    """IN -> ReLU -> conv -> IN -> ReLU -> conv -> + x   (Unet_skipconnection.py:36-57)"""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.conv1 = HipConv(in_channels, in_channels)
+        self.conv2 = HipConv(in_channels, in_channels)
+
+    def forward(self, x, x_stats, want_stats=True):
+        h, hs = self.conv1(x, in_norm=x_stats, slope=0.0, want_stats=True)
+        return self.conv2(h, in_norm=hs, slope=0.0, residual=x, want_stats=want_stats)
+
+
+class EnDown(nn.Module):
+    def __init__(self, in_channels, out_channels, stride=2):
+        super().__init__()
+        self.conv = HipConv(in_channels, out_channels, stride=stride)
+
+    def forward(self, x, want_stats=True):
+        return self.conv(x, want_stats=want_stats)
+
+
+class Unet(nn.Module):
+    def __init__(self, in_channels=4, base_channels=16, num_classes=4):
+        super().__init__()
+        c = base_channels
+        self.InitConv = InitConv(in_channels, c, dropout=0.2)
+        self.EnBlock1 = EnBlock(c)
+        self.EnBlock1_1 = EnBlock(c)
+        self.EnDown1 = EnDown(c, 2 * c)
+        self.EnBlock2_1 = EnBlock(2 * c)
+        self.EnBlock2_2 = EnBlock(2 * c)
+        self.EnDown2 = EnDown(2 * c, 4 * c)
+        self.EnBlock3_1 = EnBlock(4 * c)
+        self.EnBlock3_2 = EnBlock(4 * c)
+        self.EnDown3 = EnDown(4 * c, 8 * c)
+        self.EnBlock4_1 = EnBlock(8 * c)
+        self.EnBlock4_2 = EnBlock(8 * c)
+        self.EnDown_4 = EnDown(8 * c, 16 * c, stride=1)
+
+    def forward(self, x, stem_keep=None):
+        x, s = self.InitConv(x, stem_keep)
+        x, s = self.EnBlock1(x, s)
+        x1, _ = self.EnBlock1_1(x, s, want_stats=False)
+        x, s = self.EnDown1(x1)
+        x, s = self.EnBlock2_1(x, s)
+        x2, _ = self.EnBlock2_2(x, s, want_stats=False)
+        x, s = self.EnDown2(x2)
+        x, s = self.EnBlock3_1(x, s)
+        x3, _ = self.EnBlock3_2(x, s, want_stats=False)
+        x, s = self.EnDown3(x3)
+        x, s = self.EnBlock4_1(x, s)
+        x, _ = self.EnBlock4_2(x, s, want_stats=False)
+        x4, _ = self.EnDown_4(x, want_stats=False)
+        return x1, x2, x3, x4

@@ -1,0 +1,44 @@
+"""Sub-region and edge supervision heads (reference SuperviseLabel.py:6-81, EdgeSuperviseLabel.py:5-76):
+conv3 -> conv3 -> trilinear upsample -> softmax over 2 channels, per sub-region k in {1,2,4}.
+The 2-channel logits live in a 4-channel zero-padded buffer (16-byte voxel rows); upsample + softmax is one
+kernel (cwf_upsample_softmax) writing the returned probability map once."""
+import torch.nn as nn
+
+from cwf import functional as CF
+from .layers import HipConv
+
+
+class _Heads(nn.Module):
+    def _head(self, first, second, x):
+        h, _ = first(x)
+        logit, _ = second(h)                      # [N,d,h,w,4], channels 2..3 zero
+        prob = CF.upsample_softmax(logit, 2, self.sample_scale)
+        return prob.permute(0, 4, 1, 2, 3)        # logical [N,2,D,H,W], channels-last memory
+
+
+class SuperviseLabel(_Heads):
+    def __init__(self, item_future_num):
+        super().__init__()
+        for k in (1, 2, 4):
+            setattr(self, "supervise_label_%d" % k, HipConv(item_future_num, 32))
+            setattr(self, "down_label_%d" % k, HipConv(32, 2))
+        self.sample_scale = 8
+
+    def forward(self, s01, s02, s04):
+        return {"01": self._head(self.supervise_label_1, self.down_label_1, s01),
+                "02": self._head(self.supervise_label_2, self.down_label_2, s02),
+                "04": self._head(self.supervise_label_4, self.down_label_4, s04)}
+
+
+class EdgeSuperviseLabel(_Heads):
+    def __init__(self, item_future_num):
+        super().__init__()
+        for k in (1, 2, 4):
+            setattr(self, "edge_supervise_label_%d" % k, HipConv(item_future_num, 8))
+            setattr(self, "edge_down_label_%d" % k, HipConv(8, 2))
+        self.sample_scale = 4
+
+    def forward(self, e01, e02, e04):
+        return {"01": self._head(self.edge_supervise_label_1, self.edge_down_label_1, e01),
+                "02": self._head(self.edge_supervise_label_2, self.edge_down_label_2, e02),
+                "04": self._head(self.edge_supervise_label_4, self.edge_down_label_4, e04)}

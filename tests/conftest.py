@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, "decouple-and-couple_learning_in_multi-modal_brain_tumor_segmentation_amd")
+GOLDEN = os.path.join(REPO, "tests", "golden")
+for p in (PKG, REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture()
+def emul_backend():
+    """Inject the CPU kernel emulation (oracle/kernel_emul.py) for host-logic tests; restored afterwards."""
+    from cwf import kernels
+    from oracle.kernel_emul import EmulBackend
+    old = kernels._backend
+    kernels._set_backend_for_testing(EmulBackend())
+    yield
+    kernels._set_backend_for_testing(old)
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The real backend; only GPU tests may ask for it."""
+    import torch
+    from cwf import kernels
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    kernels._set_backend_for_testing(None)
+    return kernels.backend()

@@ -1,0 +1,108 @@
+"""CPU: the package's module tree + autograd glue, driven through the kernel EMULATION (oracle/kernel_emul.py),
+against the oracle model and the golden fixtures.  This checks everything except the HIP kernels themselves
+(those are compared with the same emulation in the -m gpu tests)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import reference_model as rm
+from utils import synthetic as syn
+
+
+def _model():
+    from models.clswiseformer.cls_wise_former import get_cls_wise_former
+    m = get_cls_wise_former(dataset="brats", _conv_repr=True, _pe_type="fixed")
+    m.load_state_dict(syn.det_state_dict(rm.param_shapes()), strict=False)
+    m.Unet_list.InitConv.dropout = 0.0
+    return m
+
+
+def test_state_dict_layout_matches_reference():
+    from models.clswiseformer.cls_wise_former import get_cls_wise_former
+    m = get_cls_wise_former(dataset="brats", _conv_repr=True, _pe_type="fixed")
+    sd = m.state_dict()
+    assert list(sd.keys()) == [n for n, _, _ in rm.param_shapes()]
+    for n, shp, _ in rm.param_shapes():
+        assert tuple(sd[n].shape) == tuple(shp), n
+    assert torch.equal(sd["fusion_label_pos.pe"], rm.fixed_pe_table())
+    assert sum(p.numel() for p in m.parameters()) == 16824556
+    # checkpoint layout of train_no_amp.py:248-253 ('module.' prefix from the DDP wrapper) loads through DataParallel-style prefixing
+    wrapped = {"module." + k: v for k, v in sd.items()}
+    m.load_state_dict({k[len("module."):]: v for k, v in wrapped.items()})
+
+
+def test_forward_needs_hip_library_or_gpu():
+    """The product path must fail loudly without the HIP backend (no CPU fallback)."""
+    from cwf import kernels, _lib
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    old = kernels._backend
+    kernels._set_backend_for_testing(None)
+    try:
+        with pytest.raises(_lib.CwfError):
+            _model()(torch.zeros(1, 4, 64, 64, 64), None)
+    finally:
+        kernels._set_backend_for_testing(old)
+
+
+def test_model_and_losses_64_vs_oracle_and_golden(emul_backend):
+    from models import criterions
+    from utils import tools
+    g = np.load(os.path.join(GOLDEN, "model_64.npz"))
+    m = _model().eval()
+    m.collect_aux = True
+    x, target, edge = syn.synthetic_batch([0], (64, 64, 64))
+    outs = m(x, None)
+    assert outs[0].shape == (1, 4, 64, 64, 64) and outs[1]["01"].shape == (1, 2, 64, 64, 64)
+    prob = outs[0].reshape(-1)
+    assert np.allclose(prob[g["prob_sample_idx"]].detach().numpy(), g["prob_sample"], atol=5e-6)
+    for k in ("01_edge", "02_sem", "04_edge_supp", "fusion"):
+        assert set(m.aux[k][0].tolist()) == set(g["topk_" + k][0].tolist()), k
+    parts = [criterions.softmax_dice(outs[0], target), tools.get_separate_loss(outs[1], target),
+             tools.get_edge_separate_loss(outs[2], edge), tools.get_separate_loss(outs[3], target),
+             tools.get_edge_separate_loss(outs[4], edge)]
+    assert np.allclose([float(v) for v in parts], g["loss_parts"], rtol=2e-6)
+    sum(parts).backward()
+    names = list(g["grad_names"])
+    l2, noise = g["grad_l2_f64"], g["grad_noise_ref32"]
+    for n, p in m.named_parameters():
+        i = names.index(n)
+        assert p.grad is not None, n
+        if l2[i] > 1e-7:      # conv biases in front of an InstanceNorm have zero true gradient
+            got = float(p.grad.double().norm())
+            assert abs(got - l2[i]) <= max(10 * noise[i], 2e-3) * l2[i], (n, got, l2[i])
+    for key in g.files:
+        if key.startswith("grad::"):
+            n = key[6:]
+            ref = torch.from_numpy(g[key]).double()
+            got = dict(m.named_parameters())[n].grad.double()
+            if float(ref.norm()) > 1e-7:
+                assert float((got - ref).norm() / ref.norm()) < max(10 * noise[names.index(n)], 2e-3), n
+
+
+def test_batch_two_equals_two_single_samples(emul_backend):
+    m = _model().eval()
+    x, _, _ = syn.synthetic_batch([0, 1], (64, 64, 64))
+    with torch.no_grad():
+        both = m(x, None)
+        one = m(x[1:2], None)
+    assert torch.allclose(both[0][1:2], one[0], atol=1e-6)
+    assert torch.allclose(both[2]["04"][1:2], one[2]["04"], atol=1e-6)
+
+
+def test_training_mode_dropout_runs(emul_backend):
+    from models import criterions
+    m = _model().train()
+    m.Unet_list.InitConv.dropout = 0.2
+    from utils import tools
+    x, target, edge = syn.synthetic_batch([0], (64, 64, 64))
+    torch.manual_seed(1)
+    out = m(x, None)
+    loss = criterions.softmax_dice(out[0], target) + tools.get_separate_loss(out[1], target) + \
+        tools.get_edge_separate_loss(out[2], edge) + tools.get_separate_loss(out[3], target) + \
+        tools.get_edge_separate_loss(out[4], edge)
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is not None for p in m.parameters())
