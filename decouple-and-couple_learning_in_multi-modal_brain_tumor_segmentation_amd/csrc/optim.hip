@@ -20,31 +20,30 @@ extern "C" int cwf_gather_batched(const struct cwf_gather_desc* table, int nlaye
   return 0;
 }
 
-__global__ void adam_kernel(const cwf_adam_desc* __restrict__ table, float lr, float beta1, float beta2, float eps, float wd,
-                            float bc1, float bc2_sqrt, int amsgrad) {
+__global__ void adam_kernel(const cwf_adam_desc* __restrict__ table, float step_size, float omb1, float beta2, float omb2, float eps, float wd,
+                            float bc2_sqrt, int amsgrad) {
   const cwf_adam_desc d = table[blockIdx.y];
-  const float step_size = lr / bc1;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * blockDim.x) {
     const float p = d.p[i];
-    const float g = d.g[i] + wd * p;
-    const float m = d.m[i] + (1.f - beta1) * (g - d.m[i]);          // exp_avg.lerp_(grad, 1 - beta1)
-    const float v = beta2 * d.v[i] + (1.f - beta2) * g * g;         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float g = d.g[i] + wd * p;                                 // grad.add(param, alpha=weight_decay)
+    const float m = d.m[i] + omb1 * (g - d.m[i]);                    // exp_avg.lerp_(grad, 1 - beta1)
+    const float v = beta2 * d.v[i] + omb2 * g * g;                   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
     d.m[i] = m; d.v[i] = v;
     float vv = v;
     if (amsgrad) { vv = fmaxf(d.vmax[i], v); d.vmax[i] = vv; }
     const float denom = sqrtf(vv) / bc2_sqrt + eps;
-    d.p[i] = p - step_size * (m / denom);
+    d.p[i] = p - step_size * (m / denom);                            // param.addcdiv_(exp_avg, denom, value=-step_size)
   }
 }
 
 extern "C" int cwf_adam_amsgrad(const struct cwf_adam_desc* table, int ntensors, int64_t max_n,
-                                float lr, float beta1, float beta2, float eps, float weight_decay, int step, int amsgrad, void* stream) {
+                                double lr, double beta1, double beta2, double eps, double weight_decay, int step, int amsgrad, void* stream) {
   if (!table || ntensors <= 0 || max_n <= 0 || step <= 0) return CWF_E_BADARG;
-  const float bc1 = 1.f - powf(beta1, (float)step);
-  const float bc2 = 1.f - powf(beta2, (float)step);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
   int64_t gx = cdiv64(max_n, 256); if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gx, ntensors), dim3(256), 0, cwf_stream(stream), table, lr, beta1, beta2, eps, weight_decay,
-                     bc1, sqrtf(bc2), amsgrad);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gx, ntensors), dim3(256), 0, cwf_stream(stream), table, (float)(lr / bc1), (float)(1.0 - beta1),
+                     (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)sqrt(bc2), amsgrad);
   CWF_LAUNCH_CHECK();
   return 0;
 }

@@ -200,8 +200,8 @@ int cwf_dice_ce_bwd(const float* prob, const int64_t* label, uint32_t posmask, c
  * ---------------------------------------------------------------------------------------------- */
 struct cwf_adam_desc { float* p; const float* g; float* m; float* v; float* vmax; int64_t n; };
 int cwf_adam_amsgrad(const struct cwf_adam_desc* table, int ntensors, int64_t max_n,
-                     float lr, float beta1, float beta2, float eps, float weight_decay, int step, int amsgrad,
-                     void* stream);
+                     double lr, double beta1, double beta2, double eps, double weight_decay, int step, int amsgrad,
+                     void* stream);   /* hyper-parameters in double: torch derives step_size / bias corrections in double */
 
 /* ------------------------------------------------------------------------------------------------
  * K12 / misc elementwise

@@ -1,0 +1,323 @@
+"""GPU: every HIP kernel family (through the C ABI wrappers of cwf/kernels.py) against the CPU kernel oracle
+(oracle/kernel_emul.py) on the same seeded inputs.  Tolerances are for exact-f32 MFMA chains vs oneDNN/ATen fp32:
+differences come from summation order only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from cwf import packing as pk
+from oracle.kernel_emul import EmulBackend
+
+pytestmark = pytest.mark.gpu
+E = EmulBackend()
+DEV = "cuda:0"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + int(np.prod(shape)) % 9973)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def close(got, ref, rtol=2e-5, atol=None, what=""):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    atol = atol if atol is not None else rtol * float(ref.abs().max() + 1e-30)
+    err = float((got - ref).abs().max())
+    assert err <= atol + rtol * float(ref.abs().max()), (what, err, float(ref.abs().max()))
+
+
+def _packed(spec, w):
+    from cwf import functional as CF
+    spec.to(torch.device(DEV))
+    wd = w.to(DEV).contiguous().reshape(-1)
+    spec.wpk_f.copy_(torch.where(spec.fwd_map >= 0, wd[spec.fwd_map.clamp_min(0).long()], torch.zeros((), device=DEV)))
+    spec.wpk_d.copy_(torch.where(spec.dgrad_map >= 0, wd[spec.dgrad_map.clamp_min(0).long()], torch.zeros((), device=DEV)))
+    return spec
+
+
+CONV_CASES = [
+    # op, cin, cout, size (D,H,W), batch
+    (pk.CONV3_S1, 4, 16, (8, 12, 20), 2),
+    (pk.CONV3_S1, 16, 16, (16, 16, 32), 1),
+    (pk.CONV3_S1, 32, 32, (8, 8, 16), 1),
+    (pk.CONV3_S1, 96, 32, (8, 8, 8), 1),
+    (pk.CONV3_S1, 256, 128, (4, 6, 6), 1),
+    (pk.CONV3_S1, 128, 32, (6, 4, 4), 2),
+    (pk.CONV3_S1, 32, 2, (8, 8, 8), 1),
+    (pk.CONV3_S1, 8, 2, (8, 8, 8), 1),
+    (pk.CONV3_S2, 16, 32, (16, 16, 32), 1),
+    (pk.CONV3_S2, 64, 128, (8, 8, 8), 2),
+    (pk.CONV3_S2, 32, 32, (10, 12, 14), 1),
+    (pk.CONV1, 256, 128, (4, 4, 8), 1),
+    (pk.CONV1, 32, 16, (8, 8, 32), 1),
+    (pk.CONV1, 16, 4, (8, 8, 16), 2),
+    (pk.CONVT2, 64, 64, (4, 4, 8), 1),
+    (pk.CONVT2, 16, 16, (6, 8, 10), 2),
+]
+
+
+@pytest.mark.parametrize("op,cin,cout,size,n", CONV_CASES)
+def test_conv_family_fwd_dgrad_wgrad(hip, op, cin, cout, size, n):
+    from cwf import functional as CF
+    torch.manual_seed(0)
+    d, h, w_ = size
+    x = rnd(n, d, h, w_, cin, seed=1)
+    wshape = (cin, cout, 2, 2, 2) if op == pk.CONVT2 else ((cout, cin, 1, 1, 1) if op == pk.CONV1 else (cout, cin, 3, 3, 3))
+    w = rnd(*wshape, seed=2, scale=1.0 / math.sqrt(cin * (27 if len(wshape) == 5 and wshape[2] == 3 else 1)))
+    b = rnd(cout, seed=3, scale=0.1)
+    in_scale = rnd(n, cin, seed=4).abs() + 0.5
+    in_shift = rnd(n, cin, seed=5)
+    out_scale = (rnd(n, cout, seed=6) > -0.5).float() * 1.25
+    spec = _packed(CF.ConvSpec(op, cin, cout), w)
+    do, ho, wo = pk.out_dims(op, d, h, w_)
+    res = rnd(n, do, ho, wo, cout, seed=7) if cout % 4 == 0 else None
+
+    # ---- forward with every epilogue / prologue feature
+    st_ref = E.new_stats(n, cout, None)
+    y_ref = E.conv(op, x, None, b, cout, in_scale, in_shift, 0.01, res, out_scale, st_ref, w_ref=w, out_channels_alloc=spec.cout_alloc)
+    st = hip.new_stats(n, cout, DEV)
+    y = hip.conv(op, x.to(DEV), spec.wpk_f, b.to(DEV), cout, in_scale.to(DEV), in_shift.to(DEV), 0.01, None if res is None else res.to(DEV), out_scale.to(DEV), st,
+                 out_channels_alloc=spec.cout_alloc)
+    close(y, y_ref, what="fwd")
+    close(st, st_ref, rtol=1e-5, what="stats")
+    # ---- plain forward (no prologue / epilogue extras)
+    y2_ref = E.conv(op, x, None, None, cout, w_ref=w, out_channels_alloc=spec.cout_alloc)
+    y2 = hip.conv(op, x.to(DEV), spec.wpk_f, None, cout, out_channels_alloc=spec.cout_alloc)
+    close(y2, y2_ref, what="fwd plain")
+
+    # ---- data gradient
+    dy = torch.zeros(n, do, ho, wo, spec.cout_alloc)
+    dy[..., :cout] = rnd(n, do, ho, wo, cout, seed=8)
+    dx_ref = E.conv(pk.dgrad_op(op), dy, None, None, cin, out=torch.empty(n, d, h, w_, cin), w_ref=w, fwd_op=op)
+    dx = hip.conv(pk.dgrad_op(op), dy.to(DEV), spec.wpk_d, None, cin, out=torch.empty((n, d, h, w_, cin), device=DEV))
+    close(dx, dx_ref, what="dgrad")
+
+    # ---- weight / bias gradient with the recomputed prologue
+    dyv = dy[..., :cout]
+    gw_ref, gb_ref = E.wgrad(op, x, in_scale, in_shift, 0.0, dyv, cout, None, spec.b_map, w.numel(), w_ref_shape=w.shape)
+    gw, gb = hip.wgrad(op, x.to(DEV), in_scale.to(DEV), in_shift.to(DEV), 0.0, dy.to(DEV)[..., :cout], cout, spec.w_map, spec.b_map, w.numel())
+    close(gw, gw_ref, rtol=5e-5, what="wgrad")
+    if gb is not None:
+        close(gb, gb_ref, rtol=5e-5, what="bgrad")
+
+
+def test_gather_batched_matches_index_maps(hip):
+    from cwf import functional as CF
+    packer = CF.WeightPacker()
+    ws = []
+    for op, cin, cout in ((pk.CONV3_S1, 16, 32), (pk.CONV1, 32, 16), (pk.CONVT2, 16, 16), (pk.CONV3_S2, 32, 64)):
+        shape = (cin, cout, 2, 2, 2) if op == pk.CONVT2 else ((cout, cin, 1, 1, 1) if op == pk.CONV1 else (cout, cin, 3, 3, 3))
+        w = torch.nn.Parameter(rnd(*shape, seed=cin + cout).to(DEV))
+        spec = CF.ConvSpec(op, cin, cout)
+        packer.add(spec, w)
+        ws.append((spec, w))
+    packer.refresh()
+    for spec, w in ws:
+        flat = w.detach().reshape(-1)
+        for buf, mp in ((spec.wpk_f, spec.fwd_map), (spec.wpk_d, spec.dgrad_map)):
+            ref = torch.where(mp >= 0, flat[mp.clamp_min(0).long()], torch.zeros((), device=DEV))
+            assert torch.equal(buf, ref)
+
+
+@pytest.mark.parametrize("c,shape", [(16, (2, 8, 8, 16)), (96, (1, 4, 6, 8)), (384, (1, 4, 4, 4)), (128, (2, 5, 3, 7))])
+def test_instance_norm_pieces(hip, c, shape):
+    n, d, h, w = shape
+    x = rnd(n, d, h, w, c, seed=1) + 0.3
+    st_ref = E.in_stats(x)
+    st = hip.in_stats(x.to(DEV))
+    close(st, st_ref, rtol=1e-6, what="stats")
+    sc_ref, sh_ref = E.in_finalize(st_ref, d * h * w)
+    sc, sh = hip.in_finalize(st, d * h * w)
+    close(sc, sc_ref, rtol=1e-5); close(sh, sh_ref, rtol=1e-5)
+    res = rnd(n, d, h, w, c, seed=2)
+    close(hip.norm_act_add(x.to(DEV), sc, sh, 0.01, res.to(DEV)), E.norm_act_add(x, sc_ref, sh_ref, 0.01, res), what="norm_act_add")
+    dy = rnd(n, d, h, w, c, seed=3)
+    for slope in (0.0, 0.01):
+        close(hip.in_bwd(dy.to(DEV), x.to(DEV), sc, sh, slope), E.in_bwd(dy, x, sc_ref, sh_ref, slope), rtol=5e-5, what="in_bwd")
+    # against autograd of the reference op chain
+    xr = x.clone().requires_grad_(True)
+    y = torch.nn.functional.leaky_relu(torch.nn.functional.instance_norm(xr.permute(0, 4, 1, 2, 3)), 0.01)
+    y.backward(dy.permute(0, 4, 1, 2, 3))
+    close(hip.in_bwd(dy.to(DEV), x.to(DEV), sc, sh, 0.01), xr.grad, rtol=1e-4, what="in_bwd vs autograd")
+
+
+def test_layernorm_linear_attention(hip):
+    from cwf import functional as CF
+    from cwf import kernels
+    b, t, e = 2, 129, 512
+    x = rnd(b, t, e, seed=1).to(DEV).requires_grad_(True)
+    x2 = rnd(b, 70, e, seed=2).to(DEV).requires_grad_(True)
+    gam = (rnd(e, seed=3) * 0.1 + 1).to(DEV).requires_grad_(True)
+    bet = (rnd(e, seed=4) * 0.1).to(DEV).requires_grad_(True)
+    wqkv = (rnd(3 * e, e, seed=5) / math.sqrt(e)).to(DEV).requires_grad_(True)
+    wo = (rnd(e, e, seed=6) / math.sqrt(e)).to(DEV).requires_grad_(True)
+    bo = (rnd(e, seed=7) * 0.1).to(DEV).requires_grad_(True)
+    params = [x, x2, gam, bet, wqkv, wo, bo]
+
+    def run(use_hip):
+        kernels._set_backend_for_testing(None if use_hip else E)
+        ps = params if use_hip else [p.detach().cpu().requires_grad_(True) for p in params]
+        x_, x2_, g_, b_, wq_, wo_, bo_ = ps
+        a = CF.layer_norm(x_, g_, b_)
+        c = CF.layer_norm(x2_, g_, b_)
+        q = CF.linear(a, wq_[:e])
+        kv = CF.linear(c, wq_[e:])
+        o = CF.attention_core(q, kv, 8)
+        y = CF.linear(o, wo_, bo_, residual=x_)
+        z = CF.linear(y, wo_, bo_, act=1)
+        (z * torch.linspace(-1, 1, z.numel(), device=z.device).reshape(z.shape)).sum().backward()
+        return z, [p.grad for p in ps]
+    try:
+        z_h, g_h = run(True)
+        z_e, g_e = run(False)
+    finally:
+        kernels._set_backend_for_testing(None)
+    close(z_h, z_e, rtol=2e-5, what="attn fwd")
+    for gh, ge, nm in zip(g_h, g_e, "x x2 gamma beta wqkv wo bo".split()):
+        close(gh, ge, rtol=1e-4, what="attn grad " + nm)
+    # and against plain torch of the reference's DualSelfAttention
+    from oracle import reference_model as rm
+    p = {"a.qkv.weight": wqkv.detach().cpu(), "a.out_proj.weight": wo.detach().cpu(), "a.out_proj.bias": bo.detach().cpu()}
+    xa = torch.nn.functional.layer_norm(x.detach().cpu(), (e,), gam.detach().cpu(), bet.detach().cpu())
+    xb = torch.nn.functional.layer_norm(x2.detach().cpu(), (e,), gam.detach().cpu(), bet.detach().cpu())
+    y_ref = rm.dual_attention(p, "a", xa, xb) + x.detach().cpu()
+    z_ref = torch.nn.functional.gelu(torch.nn.functional.linear(y_ref, p["a.out_proj.weight"], p["a.out_proj.bias"]))
+    close(z_h, z_ref, rtol=2e-5, what="attn vs reference restatement")
+
+
+@pytest.mark.parametrize("T", [1024, 2048, 129, 4800])
+def test_scores_topk_gather_scatter(hip, T):
+    b, e, k = 2, 512, 128 if T >= 128 else 64
+    feats = rnd(b, T, e, seed=T)
+    tok = rnd(1, 1, e, seed=1)
+    sc_ref = E.token_scores(feats, tok)
+    sc = hip.token_scores(feats.to(DEV), tok.to(DEV))
+    close(sc, sc_ref, rtol=1e-5, what="scores")
+    idx = hip.topk(sc, k)
+    idx_same_scores = E.topk(sc.cpu(), k)
+    assert torch.equal(idx.cpu(), idx_same_scores), "top-k (sorted, ties by index) differs on identical scores"
+    ref_top = torch.topk(sc_ref, k, dim=1).indices
+    assert all(len(set(idx[i].tolist()) ^ set(ref_top[i].tolist())) <= 2 for i in range(b))
+    # duplicates / ties
+    tie = torch.zeros(1, 300); tie[0, 5] = 1.0
+    assert hip.topk(tie.to(DEV), 4).cpu().tolist() == [[5, 0, 1, 2]]
+    keep = (rnd(b, k, e, seed=3) > -0.8).float() * 1.1
+    head = rnd(b, 1, e, seed=4)
+    seq = hip.gather_tokens(feats.to(DEV), idx, head.to(DEV), keep.to(DEV), 1.0)
+    close(seq, E.gather_tokens(feats, idx.cpu(), head, keep, 1.0), rtol=1e-6, what="gather")
+    dseq = rnd(b, k + 1, e, seed=5)
+    df, dh = torch.zeros(b, T, e, device=DEV), torch.zeros(1, 1, e, device=DEV)
+    hip.gather_tokens_bwd(dseq.to(DEV), idx, keep.to(DEV), df, dh)
+    df_r, dh_r = torch.zeros(b, T, e), torch.zeros(1, 1, e)
+    E.gather_tokens_bwd(dseq, idx.cpu(), keep, df_r, dh_r)
+    close(df, df_r, rtol=1e-6); close(dh, dh_r, rtol=1e-5)
+    res = rnd(b, 2 * k + 2, e, seed=6)
+    rows, gate = res[:, 1:k + 1], res[:, 0:1]
+    resd = res.to(DEV)
+    for g_ in (None, gate):
+        out = hip.scatter_rows(feats.to(DEV), idx, resd[:, 1:k + 1], None if g_ is None else resd[:, 0:1])
+        close(out, E.scatter_rows(feats, idx.cpu(), rows, g_), rtol=1e-6, what="scatter")
+    scat = E.scatter_rows(feats, idx.cpu(), rows, None)
+    dout = rnd(b, T, e, seed=7)
+    a1, a2, a3 = hip.scatter_rows_bwd(dout.to(DEV), idx, scat.to(DEV), resd[:, 0:1], k)
+    r1, r2, r3 = E.scatter_rows_bwd(dout, idx.cpu(), scat, gate, k)
+    close(a1, r1, rtol=1e-6); close(a2, r2, rtol=1e-6); close(a3, r3, rtol=1e-4, what="dgate")
+
+
+@pytest.mark.parametrize("c,size,patch", [(128, (8, 8, 8), (2, 2, 1)), (32, (16, 16, 16), (4, 2, 2)), (128, (20, 24, 20), (2, 2, 1))])
+def test_window_token_reshapes(hip, c, size, patch):
+    d, h, w = size
+    x = rnd(2, d, h, w, c, seed=1)
+    tok = hip.window_to_tokens(x.to(DEV), patch)
+    assert torch.equal(tok.cpu(), E.window_to_tokens(x, patch))
+    assert torch.equal(hip.tokens_to_window(tok, size, c, patch).cpu(), x)
+    # against the reference's convert_dim on NCDHW
+    from oracle import reference_model as rm
+    assert torch.equal(tok.cpu(), rm.convert_dim(x.permute(0, 4, 1, 2, 3), patch))
+
+
+@pytest.mark.parametrize("scale,lo", [(8, (4, 4, 4)), (4, (8, 8, 8)), (8, (5, 6, 5))])
+def test_upsample_softmax_heads(hip, scale, lo):
+    n = 2
+    logit = torch.zeros(n, *lo, 4)
+    logit[..., :2] = rnd(n, *lo, 2, seed=1) * 3
+    p = hip.upsample_softmax(logit.to(DEV), 2, scale)
+    p_ref = E.upsample_softmax(logit, 2, scale)
+    close(p, p_ref, rtol=2e-6, atol=2e-6, what="upsample fwd")
+    dprob = rnd(*p_ref.shape, seed=2)
+    dl = hip.upsample_softmax_bwd(dprob.to(DEV), p, (n,) + lo, 2, scale, 4)
+    close(dl, E.upsample_softmax_bwd(dprob, p_ref, (n,) + lo, 2, scale, 4), rtol=2e-5, what="upsample bwd")
+    assert float(dl[..., 2:].abs().max()) == 0.0
+    l4 = rnd(n, 6, 6, 6, 4, seed=3) * 2
+    p4 = hip.channel_softmax(l4.to(DEV), 4)
+    close(p4, E.channel_softmax(l4, 4), rtol=1e-6, atol=1e-7)
+    d4 = rnd(n, 6, 6, 6, 4, seed=4)
+    close(hip.channel_softmax_bwd(d4.to(DEV), p4), E.channel_softmax_bwd(d4, p4.cpu()), rtol=1e-5)
+
+
+def test_losses_against_reference_fixture(hip):
+    """The HIP Dice/CE path on the reference's own golden losses (tests/golden/losses.npz, produced by the imported
+    reference utils.tools / models.criterions)."""
+    import os
+    from conftest import GOLDEN
+    from models import criterions
+    from utils import tools
+    g = np.load(os.path.join(GOLDEN, "losses.npz"))
+    target, edge = torch.from_numpy(g["target"]).to(DEV), torch.from_numpy(g["edge"]).to(DEV)
+    p4 = torch.from_numpy(g["p4"]).to(DEV).requires_grad_(True)
+    l = criterions.softmax_dice(p4, target)
+    l.backward()
+    assert abs(float(l) - float(g["softmax_dice"])) < 2e-6
+    close(p4.grad, torch.from_numpy(g["softmax_dice_grad"]), rtol=1e-5, what="softmax_dice grad")
+    outs = {r: torch.from_numpy(g["p2_" + r]).to(DEV).requires_grad_(True) for r in ("01", "02", "04")}
+    ls = tools.get_separate_loss(outs, target)
+    ls.backward()
+    assert abs(float(ls) - float(g["separate_loss"])) < 5e-6
+    for r in outs:
+        close(outs[r].grad, torch.from_numpy(g["sep_grad_" + r]), rtol=1e-5, what="sep grad")
+        outs[r].grad = None
+    le = tools.get_edge_separate_loss(outs, edge)
+    le.backward()
+    assert abs(float(le) - float(g["edge_separate_loss"])) < 5e-6
+    for r in outs:
+        close(outs[r].grad, torch.from_numpy(g["edge_grad_" + r]), rtol=1e-5, what="edge grad")
+
+
+def test_loss_edge_cases(hip):
+    """Empty classes (a class absent from a sample), probabilities on both sides of the 0.005 clamp."""
+    from models import criterions
+    n, s = 2, 8
+    target = torch.zeros(n, s, s, s, dtype=torch.int64)
+    target[1, :2] = 3
+    prob = torch.full((n, 4, s, s, s), 0.25)
+    prob[0, 0] = 0.994; prob[0, 1:] = 0.002
+    from oracle import reference_model as rm
+    pr = prob.clone().requires_grad_(True)
+    lr = rm.softmax_dice(pr, target); lr.backward()
+    pg = prob.to(DEV).requires_grad_(True)
+    lg = criterions.softmax_dice(pg, target.to(DEV)); lg.backward()
+    assert abs(float(lr) - float(lg)) < 2e-6
+    close(pg.grad, pr.grad, rtol=1e-5, what="clamped grad")
+
+
+def test_fused_adam_against_torch_fixture(hip):
+    import os
+    from conftest import GOLDEN
+    from cwf.optim import FusedAdam
+    g = np.load(os.path.join(GOLDEN, "adam.npz"))
+    w = torch.nn.Parameter(torch.from_numpy(g["p0"]).to(DEV))
+    w2 = torch.nn.Parameter(torch.from_numpy(g["p0"]).to(DEV).clone())
+    opt = FusedAdam([w, w2], lr=2e-4, weight_decay=1e-5, amsgrad=True)
+    for i in range(3):
+        w.grad = torch.from_numpy(g["grads"][i]).to(DEV)
+        w2.grad = torch.from_numpy(g["grads"][i]).to(DEV)
+        opt.step()
+        close(w, torch.from_numpy(g["traj"][i]), rtol=1e-6, atol=1e-7, what="adam step %d" % i)
+    assert torch.equal(w, w2)
+    st = opt.state[w]
+    close(st["exp_avg"], torch.from_numpy(g["exp_avg"]), rtol=1e-6)
+    close(st["max_exp_avg_sq"], torch.from_numpy(g["max_exp_avg_sq"]), rtol=1e-6)
+    sd = opt.state_dict()     # torch.optim.Adam-compatible layout (train_no_amp.py:252 'optim_dict')
+    assert set(sd["state"][0].keys()) >= {"step", "exp_avg", "exp_avg_sq", "max_exp_avg_sq"}
