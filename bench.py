@@ -1,0 +1,195 @@
+"""bench.py -- training volumes/sec of the ClsWiseFormer hot path on MI355X (BASELINE.json metric).
+
+One "step" = forward + 5 losses + backward + Adam(amsgrad) on a rank-local batch of 2 synthetic 4-modality 128^3
+volumes (BASELINE.json configs[1]; for N > 1 the same per-rank batch = weak scaling, gradients averaged over ranks by
+bucketed RCCL all-reduce overlapped with backward).  Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     -- the dominant kernel (3x3x3 conv 16->16 @128^3, cwf_conv_mfma): algorithmic FLOPs per launch / average
+                  launch duration measured here with HIP events on the launch stream, against the dense fp32 MFMA peak
+  cpu_baseline -- the CPU oracle (oracle/reference_model.py, kind "port") timed on this box's host cores, B=1 128^3.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, "decouple-and-couple_learning_in_multi-modal_brain_tumor_segmentation_amd")
+for p in (PKG, REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+HBM_PEAK_GBS = 8000.0
+FLOP_PER_TRAIN_VOLUME = 1.594e12   # 3 x 531.3 GFLOP per 128^3 volume
+
+
+def log(msg):
+    print("[bench %s] %s" % (time.strftime("%H:%M:%S"), msg), file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """Host threads this process may really use: CPU affinity capped by the cgroup CPU quota (the GPU boxes expose every
+    host core in the affinity mask but grant a share of them; oversubscribing OpenMP threads is catastrophically slow)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def dominant_kernel_roofline(dev, iters=20):
+    """cwf_conv_mfma on the shape that dominates the step: 3x3x3, 16->16 channels, 128^3, batch 2, with the fused
+    InstanceNorm+ReLU prologue and statistics epilogue it runs with inside EnBlock / DeBlock."""
+    from cwf import functional as CF, packing as pk
+    from cwf.kernels import backend
+    K = backend()
+    n, s, c = 2, 128, 16
+    x = torch.randn((n, s, s, s, c), device=dev)
+    w = torch.nn.Parameter(torch.randn((c, c, 3, 3, 3), device=dev) * 0.05)
+    b = torch.zeros(c, device=dev)
+    spec = CF.ConvSpec(pk.CONV3_S1, c, c)
+    packer = CF.WeightPacker()
+    packer.add(spec, w)
+    packer.refresh()
+    sc = torch.ones((n, c), device=dev)
+    sh = torch.zeros((n, c), device=dev)
+    y = torch.empty_like(x)
+    stats = K.new_stats(n, c, dev)
+    for _ in range(3):
+        K.conv(pk.CONV3_S1, x, spec.wpk_f, b, c, sc, sh, 0.0, None, None, stats, out=y)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        K.conv(pk.CONV3_S1, x, spec.wpk_f, b, c, sc, sh, 0.0, None, None, stats, out=y)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * 27 * c * c * n * s ** 3
+    alg_bytes = 2.0 * n * s ** 3 * c * 4          # read x once + write y once, fp32
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "conv_mfma_kernel<4,1,4> 3x3x3 16->16 @128^3 x2", "bound": "mfma", "achieved": round(achieved, 2),
+            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+            "traffic": None, "avg_launch_ms": round(ms, 4), "algorithmic_gbytes_per_s": round(alg_bytes / (ms * 1e-3) / 1e9, 1),
+            "hbm_frac_of_8TBs": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
+def cpu_baseline(steps=2):
+    """The reference train step (fwd + 5 losses + bwd + Adam amsgrad) as restated in oracle/reference_model.py, on the host
+    cores of this box: B=1, 128^3, fp32, 1 warm-up + `steps` timed steps (bounded sample of the same workload)."""
+    from oracle import reference_model as rm
+    from utils import synthetic as syn
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    log("cpu_baseline: %d host threads" % cores)
+    state = syn.det_state_dict(rm.param_shapes())
+    tr = rm.CpuTrainer(state)
+    x, target, edge = syn.synthetic_batch([0], (128, 128, 128))
+    t0 = time.time()
+    tr.step(x, target, edge)
+    log("cpu_baseline: warm-up step %.1f s" % (time.time() - t0))
+    t0 = time.time()
+    for i in range(steps):
+        tr.step(x, target, edge)
+        log("cpu_baseline: step %d done" % i)
+    dt = (time.time() - t0) / steps
+    return {"value": round(1.0 / dt, 4), "unit": "volumes/s", "cores": cores, "kind": "port",
+            "sample": "%d timed steps (+1 warm-up) of B=1 4x128^3 fwd+5 losses+bwd+Adam(amsgrad), fp32, torch CPU ops" % steps,
+            "sec_per_step": round(dt, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=2, help="rank-local batch (independent B=1 samples, SURVEY F2)")
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from models.clswiseformer.cls_wise_former import get_cls_wise_former
+    from cwf.trainer import Trainer
+    from utils import synthetic as syn
+
+    torch.manual_seed(1000 + rank)                       # train_no_amp.py:85 seed, per-rank streams
+    model = get_cls_wise_former(dataset="brats", _conv_repr=True, _pe_type="fixed").to(dev).train()   # random init, dropout ON
+    trainer = Trainer(model, lr=2e-4, weight_decay=1e-5, amsgrad=True, end_epoch=1000)
+    size = (args.size,) * 3
+    idx = [rank * args.batch + i for i in range(args.batch)]
+    x, target, edge = syn.synthetic_batch(idx, size)
+    x, target, edge = x.to(dev), target.to(dev), edge.to(dev)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    log("rank %d: model + inputs ready" % rank)
+    for i in range(args.warmup):
+        trainer.step(x, target, edge, epoch=0)
+        torch.cuda.synchronize()
+        log("rank %d: warm-up step %d done" % (rank, i))
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, _ = trainer.step(x, target, edge, epoch=0)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss)
+    log("rank %d: timed %d steps in %.3f s" % (rank, args.steps, dt))
+
+    if rank == 0:
+        vols = world * args.batch * args.steps
+        value = vols / dt
+        out = {
+            "metric": "training volumes/sec (4x128^3)", "value": round(value, 3), "unit": "volumes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 1xMI355X, batch %d per GPU, 4-modality %d^3 synthetic BraTS patches; "
+                                   "fwd + softmax_dice + 4 sub-region/edge losses + bwd + Adam(amsgrad); random-init weights, dropout on"
+                                   % (args.batch, args.size),
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "arithmetic": "fp32 in / fp32 MFMA accumulate"},
+            "final_loss": round(final_loss, 5),
+            "end_to_end": {"tflops": round(value * FLOP_PER_TRAIN_VOLUME * (args.size / 128.0) ** 3 / 1e12, 2),
+                           "frac_fp32_mfma_peak": round(value * FLOP_PER_TRAIN_VOLUME * (args.size / 128.0) ** 3 / 1e12 / world / FP32_MFMA_PEAK_TFLOPS, 4)},
+        }
+        out["roofline"] = dominant_kernel_roofline(dev)
+        log("roofline leg done: %s" % json.dumps(out["roofline"]))
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
