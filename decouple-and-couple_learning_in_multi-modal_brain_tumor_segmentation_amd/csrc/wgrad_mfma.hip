@@ -131,17 +131,33 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgArgs a) {
   }
 }
 
-// out[e] = sum_s partial[s][map[e]]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int64_t slab,
-                                    const int32_t* __restrict__ w_map, float* __restrict__ dW, int64_t w_count,
-                                    const int32_t* __restrict__ b_map, float* __restrict__ db, int64_t b_count) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= w_count + b_count) return;
-  const bool isw = e < w_count;
-  const int32_t m = isw ? w_map[e] : b_map[e - w_count];
-  float s = 0.f;
-  if (m >= 0) for (int k = 0; k < nsplit; ++k) s += partial[(int64_t)k * slab + m];
-  if (isw) dW[e] = s; else db[e - w_count] = s;
+// Sum the slabs in SLAB order (every load is a coalesced 16-B read; the nsplit loads of a thread are independent and
+// pipeline) and scatter the 4 sums through the inverse map: inv >= 0 -> dW index, inv <= -2 -> bias index (-2 - inv),
+// -1 -> padding.  Fixed summation order: bitwise reproducible.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int64_t slab,
+                                                          const int32_t* __restrict__ inv, float* __restrict__ dW, float* __restrict__ db) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // float4 index inside the slab
+  if (q * 4 >= slab) return;
+  const float4* p = reinterpret_cast<const float4*>(partial) + q;
+  const int64_t stride4 = slab >> 2;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int k = 0;
+  for (; k + 4 <= nsplit; k += 4) {
+    const float4 a0 = p[(int64_t)k * stride4], a1 = p[(int64_t)(k + 1) * stride4], a2 = p[(int64_t)(k + 2) * stride4], a3 = p[(int64_t)(k + 3) * stride4];
+    s.x += a0.x; s.y += a0.y; s.z += a0.z; s.w += a0.w;
+    s.x += a1.x; s.y += a1.y; s.z += a1.z; s.w += a1.w;
+    s.x += a2.x; s.y += a2.y; s.z += a2.z; s.w += a2.w;
+    s.x += a3.x; s.y += a3.y; s.z += a3.z; s.w += a3.w;
+  }
+  for (; k < nsplit; ++k) { const float4 a0 = p[(int64_t)k * stride4]; s.x += a0.x; s.y += a0.y; s.z += a0.z; s.w += a0.w; }
+  const int4 m = reinterpret_cast<const int4*>(inv)[q];
+  const int mm[4] = {m.x, m.y, m.z, m.w};
+  const float ss[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (mm[i] >= 0) dW[mm[i]] = ss[i];
+    else if (mm[i] <= -2 && db) db[-2 - mm[i]] = ss[i];
+  }
 }
 
 namespace {
@@ -162,7 +178,7 @@ int make_plan(WgPlan& p, int op, int N, int Di, int Hi, int Wi, int Cin, int x_l
   p.slab = blocks * 256;
   p.total = N * p.g.tiles_d * p.g.tiles_h * p.g.tiles_w;
   const int nblk = p.nchunks * p.ngroups * p.ncls;
-  int want = 1536 / nblk; if (want < 1) want = 1; if (want > p.total) want = p.total;
+  int want = 512 / nblk; if (want < 1) want = 1; if (want > p.total) want = p.total;
   p.tps = cdiv(p.total, want);
   p.nsplit = cdiv(p.total, p.tps);
   p.wg_splits = p.nsplit;
@@ -218,13 +234,10 @@ extern "C" int cwf_wgrad_mfma(int op, const float* x, int x_ldc, const float* in
 }
 
 extern "C" int cwf_wgrad_reduce(const float* partial, int nsplit, int64_t slab_floats,
-                                const int32_t* w_map, float* dW, int64_t w_count,
-                                const int32_t* b_map, float* db, int64_t b_count, void* stream) {
-  if (!partial || nsplit <= 0 || (w_count > 0 && (!w_map || !dW)) || (b_count > 0 && (!b_map || !db))) return CWF_E_BADARG;
-  const int64_t n = w_count + b_count;
-  if (n <= 0) return 0;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, cwf_stream(stream),
-                     partial, nsplit, slab_floats, w_map, dW, w_count, b_map, db, b_count);
+                                const int32_t* inv_map, float* dW, float* db, void* stream) {
+  if (!partial || nsplit <= 0 || slab_floats <= 0 || (slab_floats & 3) || !inv_map || !dW) return CWF_E_BADARG;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(slab_floats / 4, 256)), dim3(256), 0, cwf_stream(stream),
+                     partial, nsplit, slab_floats, inv_map, dW, db);
   CWF_LAUNCH_CHECK();
   return 0;
 }

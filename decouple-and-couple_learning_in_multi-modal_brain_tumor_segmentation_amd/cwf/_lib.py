@@ -22,7 +22,7 @@ SIGNATURES = {
     "cwf_wgrad_partial_floats": [I, I, I, I, I, I, I],
     "cwf_wgrad_slab_floats": [I, I, I],
     "cwf_wgrad_mfma": [I, P, I, P, P, F, P, I, P, I, I, I, I, I, I, I, I, I, P],
-    "cwf_wgrad_reduce": [P, I, L, P, P, L, P, P, L, P],
+    "cwf_wgrad_reduce": [P, I, L, P, P, P, P],
     "cwf_gather_batched": [P, I, L, P],
     "cwf_in_finalize": [P, P, P, I, L, F, P],
     "cwf_in_stats": [P, I, P, I, L, I, P],

@@ -28,16 +28,16 @@ class ConvSpec:
         self.cout_alloc = (cout + 3) // 4 * 4
         self.np_fwd = pk.fwd_map(op, cin, cout)
         self.np_dgrad = pk.dgrad_map(op, cin, cout, self.cout_alloc)
-        self.np_wmap, self.np_bmap, self.slab = pk.wgrad_maps(op, cin, cout)
+        self.np_inv, self.has_bias_map, self.slab = pk.wgrad_inverse_map(op, cin, cout)
         self.dev = None
-        self.fwd_map = self.dgrad_map = self.w_map = self.b_map = None
+        self.fwd_map = self.dgrad_map = self.inv_map = None
         self.wpk_f = self.wpk_d = None
 
     def to(self, device):
         if self.dev == device:
             return self
         t = lambda a: None if a is None else torch.from_numpy(a).to(device)
-        self.fwd_map, self.dgrad_map, self.w_map, self.b_map = t(self.np_fwd), t(self.np_dgrad), t(self.np_wmap), t(self.np_bmap)
+        self.fwd_map, self.dgrad_map, self.inv_map = t(self.np_fwd), t(self.np_dgrad), t(self.np_inv)
         self.wpk_f = torch.zeros(self.np_fwd.size, dtype=torch.float32, device=device)
         self.wpk_d = torch.zeros(self.np_dgrad.size, dtype=torch.float32, device=device)
         self.dev = device
@@ -106,7 +106,7 @@ class _ConvFn(torch.autograd.Function):
         dw = db = dx = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dyv = dy[..., :spec.cout] if dy.shape[-1] != spec.cout else dy
-            dwf, db = K.wgrad(spec.op, x, in_scale, in_shift, ctx.slope, dyv, spec.cout, spec.w_map, spec.b_map, w.numel(), w_ref_shape=w.shape)
+            dwf, db = K.wgrad(spec.op, x, in_scale, in_shift, ctx.slope, dyv, spec.cout, spec.inv_map, spec.has_bias_map, w.numel(), w_ref_shape=w.shape)
             dw = dwf.view(w.shape)
             if db is None:      # ConvTranspose: bias gradient spans the 8 parity classes
                 db = K.in_stats(dy)[:, :, 0].sum(0).float()

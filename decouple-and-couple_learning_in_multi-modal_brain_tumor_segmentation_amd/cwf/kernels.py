@@ -88,23 +88,22 @@ class HipBackend:
                    n, di, hi, wi, cin, do, ho, wo, cout, self._stream())
         return y
 
-    def wgrad(self, op, x, in_scale, in_shift, slope, dy, cout, w_map, b_map, w_numel, w_ref_shape=None):
+    def wgrad(self, op, x, in_scale, in_shift, slope, dy, cout, inv_map, has_bias_map, w_numel, w_ref_shape=None):
         """returns (dW flat [w_numel], db [cout] or None)"""
         x, x_ldc = cl(x)
-        dy, dy_ldc = cl(dy) if dy.shape[-1] % 4 == 0 or dy.stride(3) % 4 == 0 else (dy, dy.stride(3))
+        dy, dy_ldc = cl(dy)
         n, di, hi, wi, cin = x.shape
         _, do, ho, wo, _ = dy.shape
         nsplit = self.lib.cwf_wgrad_nsplit(op, n, do, ho, wo, cin, cout)
         slab = self.lib.cwf_wgrad_slab_floats(op, cin, cout)
-        if nsplit <= 0 or slab <= 0:
-            raise _lib.CwfError("cwf_wgrad plan failed (%d, %d)" % (nsplit, slab))
+        if nsplit <= 0 or slab <= 0 or slab != inv_map.numel():
+            raise _lib.CwfError("cwf_wgrad plan failed (%d, %d, %d)" % (nsplit, slab, inv_map.numel()))
         part = self.workspace("wgrad", nsplit * slab, x.device)
         self._call("cwf_wgrad_mfma", op, x.data_ptr(), x_ldc, _p(in_scale), _p(in_shift), float(slope),
                    dy.data_ptr(), dy_ldc, part.data_ptr(), n, di, hi, wi, cin, do, ho, wo, cout, self._stream())
         dw = torch.empty(w_numel, dtype=_f32, device=x.device)
-        db = torch.empty(cout, dtype=_f32, device=x.device) if b_map is not None else None
-        self._call("cwf_wgrad_reduce", part.data_ptr(), nsplit, slab, w_map.data_ptr(), dw.data_ptr(), w_numel,
-                   _p(b_map), _p(db), cout if b_map is not None else 0, self._stream())
+        db = torch.empty(cout, dtype=_f32, device=x.device) if has_bias_map else None
+        self._call("cwf_wgrad_reduce", part.data_ptr(), nsplit, slab, inv_map.data_ptr(), dw.data_ptr(), _p(db), self._stream())
         return dw, db
 
     def gather_batched(self, table, nlayers, max_n):

@@ -141,3 +141,13 @@ def out_dims(op, d, h, w):
     if op == CONVT2:
         return (2 * d, 2 * h, 2 * w)
     return (d, h, w)
+
+
+def wgrad_inverse_map(op, cin, cout):
+    """(inv, has_bias, slab_floats): inv[slab index] = index into dW.flat, or -2 - co for the bias row, or -1 (padding)."""
+    w_map, b_map, slab = wgrad_maps(op, cin, cout)
+    inv = np.full(slab, -1, dtype=np.int32)
+    inv[w_map] = np.arange(w_map.size, dtype=np.int32)
+    if b_map is not None:
+        inv[b_map] = -2 - np.arange(b_map.size, dtype=np.int32)
+    return inv, b_map is not None, slab

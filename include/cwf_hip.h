@@ -67,9 +67,9 @@ int cwf_conv_mfma(int op,
 /* Weight gradient (+ bias gradient) of the same family (op in {CONV3_S1, CONV3_S2, CONV1, CONVT2}):
  *   dW[tap][ci][co] = sum_{n,vox} act(x*in_scale+in_shift)[n, vox*is+tap, ci] * dy[n, vox, co]
  * in two launches: cwf_wgrad_mfma writes `nsplit` partial slabs (MFMA accumulator layout) into `partial`
- * (cwf_wgrad_partial_floats() floats); cwf_wgrad_reduce sums the slabs and scatters into the reference
- * layouts through host-built index maps (dW: [Cout][Cin][k][k][k] as nn.Conv3d.weight; db: [Cout]).
- * nsplit = 0 lets the library choose; the chosen value is returned by cwf_wgrad_nsplit().            */
+ * (cwf_wgrad_partial_floats() floats); cwf_wgrad_reduce sums the slabs in slab order and scatters through a host-built
+ * INVERSE map (int32 [slab_floats]: >= 0 index into dW ([Cout][Cin][k][k][k] as nn.Conv3d.weight), <= -2 bias index
+ * -2-v into db ([Cout], may be NULL), -1 padding).  The split count is chosen by the library: cwf_wgrad_nsplit().      */
 int cwf_wgrad_nsplit(int op, int N, int Do, int Ho, int Wo, int Cin, int Cout);
 int64_t cwf_wgrad_partial_floats(int op, int N, int Do, int Ho, int Wo, int Cin, int Cout);
 int64_t cwf_wgrad_slab_floats(int op, int Cin, int Cout);
@@ -79,8 +79,7 @@ int cwf_wgrad_mfma(int op,
                    int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
                    void* stream);
 int cwf_wgrad_reduce(const float* partial, int nsplit, int64_t slab_floats,
-                     const int32_t* w_map, float* dW, int64_t w_count,
-                     const int32_t* b_map, float* db, int64_t b_count, void* stream);
+                     const int32_t* inv_map, float* dW, float* db, void* stream);
 
 /* dst[i] = map[i] >= 0 ? src[map[i]] : 0 for a table of `nlayers` descriptors resident in device memory
  * (struct cwf_gather_desc).  Used once per step to pack every layer's weights for K1.               */

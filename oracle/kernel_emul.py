@@ -90,7 +90,7 @@ class EmulBackend:
         out.copy_(g)
         return out
 
-    def wgrad(self, op, x, in_scale, in_shift, slope, dy, cout, w_map, b_map, w_numel, w_ref_shape=None):
+    def wgrad(self, op, x, in_scale, in_shift, slope, dy, cout, inv_map, has_bias_map, w_numel, w_ref_shape=None):
         """cwf_wgrad_mfma + cwf_wgrad_reduce: weight / bias halves of aten::convolution_backward on act(IN(x))."""
         xa = _prologue(x, in_scale, in_shift, slope).detach()
         w = torch.zeros(w_ref_shape, dtype=torch.float32, requires_grad=True)
@@ -98,7 +98,7 @@ class EmulBackend:
         with torch.enable_grad():
             y = _fwd_conv(op, xa, w, b)
             gw, gb = torch.autograd.grad(y, (w, b), dy.contiguous())
-        return gw.reshape(-1), (gb if b_map is not None else None)
+        return gw.reshape(-1), (gb if has_bias_map else None)
 
     def gather_batched(self, table, nlayers, max_n):
         pass    # packed buffers are unused by the emulation

@@ -96,8 +96,8 @@ def test_conv_family_fwd_dgrad_wgrad(hip, op, cin, cout, size, n):
 
     # ---- weight / bias gradient with the recomputed prologue
     dyv = dy[..., :cout]
-    gw_ref, gb_ref = E.wgrad(op, x, in_scale, in_shift, 0.0, dyv, cout, None, spec.b_map, w.numel(), w_ref_shape=w.shape)
-    gw, gb = hip.wgrad(op, x.to(DEV), in_scale.to(DEV), in_shift.to(DEV), 0.0, dy.to(DEV)[..., :cout], cout, spec.w_map, spec.b_map, w.numel())
+    gw_ref, gb_ref = E.wgrad(op, x, in_scale, in_shift, 0.0, dyv, cout, None, spec.has_bias_map, w.numel(), w_ref_shape=w.shape)
+    gw, gb = hip.wgrad(op, x.to(DEV), in_scale.to(DEV), in_shift.to(DEV), 0.0, dy.to(DEV)[..., :cout], cout, spec.inv_map, spec.has_bias_map, w.numel())
     close(gw, gw_ref, rtol=5e-5, what="wgrad")
     if gb is not None:
         close(gb, gb_ref, rtol=5e-5, what="bgrad")
