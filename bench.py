@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
+                    help="MFMA operand form of the conv family (storage and accumulation are fp32 in every mode)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,6 +134,8 @@ def main():
 
     from models.clswiseformer.cls_wise_former import get_cls_wise_former
     from cwf.trainer import Trainer
+    from cwf import kernels
+    kernels.set_precision(args.precision)
     from utils import synthetic as syn
 
     torch.manual_seed(1000 + rank)                       # train_no_amp.py:85 seed, per-rank streams

@@ -55,6 +55,7 @@ struct ConvGeom {
   int cls_ooff[8][3];
   int cls_dims[8][3];      // class grid extents (Dc,Hc,Wc)
   int cls_wbase[8];        // offset of the class in the packed weights, in 256-float blocks
+  int cls_wbase16[8];      // same for the split-bf16 packing, in blocks of 64 lanes x 32 B (tap PAIRS)
   int tapofs[64];          // LDS voxel offset of tap t of class c at [c*8+t] (ncls==8) or [t] (ncls==1)
 };
 

@@ -1,0 +1,300 @@
+// K1 (split-bf16 form) -- the conv family of conv_mfma.hip on v_mfma_f32_16x16x32_bf16.
+//
+// Activations and weights stay fp32 in HBM; only the MFMA operands are bf16:
+//   X3 = true  ("bf16x3"): x = xh + xl, w = wh + wl (bf16 each, lo = bf16(v - hi));  x.w ~= xh.wh + xh.wl + xl.wh with fp32
+//                accumulation: ~2^-16 relative per product (the dropped xl.wl term), 3 MFMAs = 5.3x the fp32 MFMA rate.
+//   X3 = false ("bf16")  : x ~= xh, w ~= wh: one MFMA, 16x the fp32 MFMA rate, 2^-9 relative per product.
+// The input halo tile is converted while it is staged (after the fused InstanceNorm + activation prologue), into two LDS
+// images [voxel][16 ch] bf16 (hi, lo): 32-byte voxel rows make the 16-byte A-fragment reads bank-conflict free.
+// K ordering: one MFMA (K = 32) = two taps x 16 channels: lane group kq reads channels 8(kq&1).. of tap 2s + (kq>>1).
+// Packed weights: [class][ci_chunk16][tap pair][co_tile16][lane64][hi 8 | lo 8] bf16 (cwf_gather_split_bf16).
+// Geometry, tiling, epilogue (bias / residual / out_scale / InstanceNorm statistics) are those of conv_mfma.hip.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct ConvArgsB {
+  ConvGeom g;
+  const float* x; const uint4* wpk; const float* bias; float* y;
+  const float* in_scale; const float* in_shift; float in_slope;
+  const float* residual; int r_ldc; const float* out_scale; double* stats;
+};
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  const __bf16 x = (__bf16)a, y = (__bf16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+__device__ __forceinline__ float bf16_round(float a) { return (float)(__bf16)a; }
+
+// Stage one 16-channel chunk as bf16 hi (and lo) images [voxel][16].
+template <bool X3>
+__device__ __forceinline__ void stage_tile_bf16(unsigned short* xh, unsigned short* xl, const ConvGeom& g, const float* x,
+                                                const float* in_scale, const float* in_shift, float slope,
+                                                int n, int chunk, int id0, int ih0, int iw0, int tid) {
+  const int q = tid & 3;
+  const int c = chunk * 16 + q * 4;
+  const bool cval = c < g.Cin;
+  const bool has_norm = in_scale != nullptr;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (has_norm && cval) {
+    sc = *reinterpret_cast<const float4*>(in_scale + (int64_t)n * g.Cin + c);
+    sh = *reinterpret_cast<const float4*>(in_shift + (int64_t)n * g.Cin + c);
+  }
+  const int nvox_in = g.ID * g.IH * g.IW;
+  for (int v = tid >> 2; v < nvox_in; v += 64) {
+    const int iw = v % g.IW; const int t2 = v / g.IW;
+    const int ih = t2 % g.IH; const int idd = t2 / g.IH;
+    const int gd = id0 + idd, gh = ih0 + ih, gw = iw0 + iw;
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cval && gd >= 0 && gd < g.Di && gh >= 0 && gh < g.Hi && gw >= 0 && gw < g.Wi) {
+      const int64_t off = ((((int64_t)n * g.Di + gd) * g.Hi + gh) * g.Wi + gw) * g.x_ldc + c;
+      val = *reinterpret_cast<const float4*>(x + off);
+      if (has_norm || slope != 1.f) {
+        val.x = cwf_act(val.x * sc.x + sh.x, slope); val.y = cwf_act(val.y * sc.y + sh.y, slope);
+        val.z = cwf_act(val.z * sc.z + sh.z, slope); val.w = cwf_act(val.w * sc.w + sh.w, slope);
+      }
+    }
+    uint2 h; h.x = pack_bf16(val.x, val.y); h.y = pack_bf16(val.z, val.w);
+    *reinterpret_cast<uint2*>(xh + v * 16 + q * 4) = h;
+    if (X3) {
+      uint2 l;
+      l.x = pack_bf16(val.x - bf16_round(val.x), val.y - bf16_round(val.y));
+      l.y = pack_bf16(val.z - bf16_round(val.z), val.w - bf16_round(val.w));
+      *reinterpret_cast<uint2*>(xl + v * 16 + q * 4) = l;
+    }
+  }
+}
+
+template <int MT, int NT, int WM, bool X3>
+__global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
+  constexpr int WN = 4 / WM;
+  extern __shared__ float4 lds4[];
+  const ConvGeom& g = a.g;
+  const int nvox_in = g.ID * g.IH * g.IW;
+  unsigned short* xh = reinterpret_cast<unsigned short*>(lds4);
+  unsigned short* xl = xh + nvox_in * 16;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 15, kq = lane >> 4;
+
+  int bx = blockIdx.x;
+  const int tile_w = bx % g.tiles_w; bx /= g.tiles_w;
+  const int tile_h = bx % g.tiles_h;
+  const int tile_d = bx / g.tiles_h;
+  const int n = blockIdx.z / g.ncls, cls = blockIdx.z % g.ncls;
+  const int Dc = g.cls_dims[cls][0], Hc = g.cls_dims[cls][1], Wc = g.cls_dims[cls][2];
+  const int od0 = tile_d * g.TD, oh0 = tile_h * g.TH, ow0 = tile_w * 16;
+  if (od0 >= Dc || oh0 >= Hc || ow0 >= Wc) return;
+  const int ntaps = g.cls_ntaps[cls];
+  const int nsteps = (ntaps + 1) >> 1;
+  const int* tapofs = g.tapofs + (g.ncls > 1 ? cls * 8 : 0);
+  const int nt0 = (blockIdx.y * WN + wn) * NT;
+
+  int abase[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int mt = wm * MT + m;
+    const int td = mt / g.TH, th = mt % g.TH;
+    abase[m] = (((td * g.is) * g.IH + th * g.is) * g.IW + r * g.is) * 16 + (kq & 1) * 8;   // bf16 element offset
+  }
+  const bool second = (kq >> 1) != 0;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int id0 = od0 * g.is + g.lo[0], ih0 = oh0 * g.is + g.lo[1], iw0 = ow0 * g.is + g.lo[2];
+
+  for (int chunk = 0; chunk < g.nchunks; ++chunk) {
+    if (chunk) __syncthreads();
+    stage_tile_bf16<X3>(xh, xl, g, a.x, a.in_scale, a.in_shift, a.in_slope, n, chunk, id0, ih0, iw0, tid);
+    __syncthreads();
+    // packed weights: block = 64 lanes x (hi 16 B | lo 16 B) = 128 uint4
+    const uint4* wchunk = a.wpk + ((int64_t)g.cls_wbase16[cls] + (int64_t)chunk * nsteps * g.ntiles) * 128 + lane * 2;
+#pragma unroll 1
+    for (int s = 0; s < nsteps; ++s) {
+      const int t0 = tapofs[2 * s];
+      const int t1 = tapofs[(2 * s + 1 < ntaps) ? 2 * s + 1 : 2 * s];     // padded tap: weights are zero, address stays valid
+      const int to = (second ? t1 : t0) * 16;
+      uint4 bh[NT], bl[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        bh[j] = make_uint4(0, 0, 0, 0); bl[j] = make_uint4(0, 0, 0, 0);
+        if (nt0 + j < g.ntiles) {
+          const uint4* p = wchunk + ((int64_t)s * g.ntiles + nt0 + j) * 128;
+          bh[j] = p[0];
+          if (X3) bl[j] = p[1];
+        }
+      }
+      uint4 ah[MT], al[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        ah[m] = *reinterpret_cast<const uint4*>(xh + abase[m] + to);
+        if (X3) al[m] = *reinterpret_cast<const uint4*>(xl + abase[m] + to);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, bh[j]), acc[m][j], 0, 0, 0);
+          if (X3) {
+            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, bl[j]), acc[m][j], 0, 0, 0);
+            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[m]), __builtin_bit_cast(bf16x8, bh[j]), acc[m][j], 0, 0, 0);
+          }
+        }
+    }
+  }
+
+  // ---- epilogue (identical to conv_mfma.hip: C/D layout is shape-determined, row = kq*4+i, col = r)
+  const int os = g.os;
+  const int of0 = g.cls_ooff[cls][0], of1 = g.cls_ooff[cls][1], of2 = g.cls_ooff[cls][2];
+  float s1[NT], s2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int co = (nt0 + j) * 16 + r;
+    if (co >= g.Cout) continue;
+    const float bv = a.bias ? a.bias[co] : 0.f;
+    const float osc = a.out_scale ? a.out_scale[(int64_t)n * g.Cout + co] : 1.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int mt = wm * MT + m;
+      const int od = od0 + mt / g.TH, oh = oh0 + mt % g.TH;
+      if (od >= Dc || oh >= Hc) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ow = ow0 + kq * 4 + i;
+        if (ow >= Wc) continue;
+        const int64_t vox = (((int64_t)n * g.Do + (od * os + of0)) * g.Ho + (oh * os + of1)) * g.Wo + (ow * os + of2);
+        float v = acc[m][j][i] + bv;
+        if (a.residual) v += a.residual[vox * a.r_ldc + co];
+        v *= osc;
+        a.y[vox * g.y_ldc + co] = v;
+        s1[j] += v; s2[j] += v * v;
+      }
+    }
+  }
+  if (a.stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds4);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float u1 = s1[j], u2 = s2[j];
+      u1 += __shfl_xor(u1, 16, 64); u1 += __shfl_xor(u1, 32, 64);
+      u2 += __shfl_xor(u2, 16, 64); u2 += __shfl_xor(u2, 32, 64);
+      if (kq == 0) {
+        red[(((wm * WN + wn) * NT + j) * 16 + r) * 2 + 0] = u1;
+        red[(((wm * WN + wn) * NT + j) * 16 + r) * 2 + 1] = u2;
+      }
+    }
+    __syncthreads();
+    if (tid < WN * NT * 16 * 2) {
+      const int which = tid & 1, rr = (tid >> 1) & 15, jj = (tid >> 5) % NT, ww = (tid >> 5) / NT;
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) s += (double)red[(((w * WN + ww) * NT + jj) * 16 + rr) * 2 + which];
+      const int co = ((blockIdx.y * WN + ww) * NT + jj) * 16 + rr;
+      if (co < g.Cout) atomic_add_f64(a.stats + ((int64_t)n * g.Cout + co) * 2 + which, s);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight packing: dst[(i/8)*16 + i%8] = hi(src[map[i]]), dst[(i/8)*16 + 8 + i%8] = lo(...)   (bf16, zeros where map < 0)
+// ---------------------------------------------------------------------------------------------------
+__global__ void gather_split_bf16_kernel(const cwf_gather_desc* __restrict__ table) {
+  const cwf_gather_desc d = table[blockIdx.y];
+  unsigned short* dst = reinterpret_cast<unsigned short*>(d.dst);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t m = d.map[i];
+    const float v = m >= 0 ? d.src[m] : 0.f;
+    const __bf16 h = (__bf16)v;
+    const __bf16 l = (__bf16)(v - (float)h);
+    const int64_t o = (i >> 3) * 16 + (i & 7);
+    dst[o] = __builtin_bit_cast(unsigned short, h);
+    dst[o + 8] = __builtin_bit_cast(unsigned short, l);
+  }
+}
+
+extern "C" int cwf_gather_split_bf16(const struct cwf_gather_desc* table, int nlayers, int64_t max_n, void* stream) {
+  if (!table || nlayers <= 0 || max_n <= 0) return CWF_E_BADARG;
+  int64_t gx = cdiv64(max_n, 256); if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(gather_split_bf16_kernel, dim3((unsigned)gx, nlayers), dim3(256), 0, cwf_stream(stream), table);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+
+namespace {
+struct TileCfg { int MT, NT, WM; };
+// same heuristic as conv_mfma.hip (kept local: the two files are independent translation units)
+TileCfg choose_cfg(int op, const int cdims[3], int ncls, int N, int ntiles) {
+  const bool s2 = (op == CWF_CONV3_S2 || op == CWF_CONVT2_DGRAD);
+  static const TileCfg all[] = {{4, 4, 1}, {2, 4, 2}, {2, 4, 4}, {4, 2, 4}, {4, 1, 4}, {1, 4, 4}, {1, 2, 4}, {1, 2, 2}, {1, 1, 4}};
+  TileCfg best = {1, 1, 4};
+  double best_score = -1.0;
+  for (const TileCfg& c : all) {
+    const int WN = 4 / c.WM, MTOT = c.MT * c.WM, NTOT = c.NT * WN;
+    if (s2 && MTOT > 4) continue;
+    int TD, TH;
+    switch (MTOT) { case 16: TD = 4; TH = 4; break; case 8: TD = 2; TH = 4; break; case 4: TD = 2; TH = 2; break; case 2: TD = 1; TH = 2; break; default: TD = 1; TH = 1; }
+    const double sp_tiles = (double)cdiv(cdims[0], TD) * cdiv(cdims[1], TH) * cdiv(cdims[2], 16);
+    const double sp_eff = ((double)cdims[0] * cdims[1] * cdims[2]) / (sp_tiles * MTOT * 16);
+    const int ngrp = cdiv(ntiles, NTOT);
+    const double n_eff = (double)ntiles / (ngrp * NTOT);
+    const double nwg = sp_tiles * ngrp * N * ncls;
+    const double fill = nwg >= 512 ? 1.0 : nwg / 512.0;
+    const double reuse = 1.0 - 0.35 / (c.MT * c.NT) - 0.1 / MTOT;
+    const double score = sp_eff * n_eff * fill * reuse;
+    if (score > best_score) { best_score = score; best = c; }
+  }
+  return best;
+}
+
+template <int MT, int NT, int WM, bool X3>
+int launch_cfg(const ConvArgsB& a, hipStream_t st) {
+  constexpr int WN = 4 / WM;
+  const ConvGeom& g = a.g;
+  const size_t lds_tile = (size_t)g.ID * g.IH * g.IW * 16 * sizeof(unsigned short) * (X3 ? 2 : 1);
+  const size_t lds_red = (size_t)4 * NT * 16 * 2 * sizeof(float);
+  const size_t lds = lds_tile > lds_red ? lds_tile : lds_red;
+  if (lds > 160 * 1024) return CWF_E_TOOLARGE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MT, NT, WM, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid(g.tiles_d * g.tiles_h * g.tiles_w, cdiv(g.ntiles, WN * NT), g.N * g.ncls);
+  hipLaunchKernelGGL((conv_bf16_kernel<MT, NT, WM, X3>), grid, dim3(256), lds, st, a);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace
+
+extern "C" int cwf_conv_mfma_bf16(int op, int x3, const float* x, int x_ldc, const void* wpk16, const float* bias,
+                                  float* y, int y_ldc, const float* in_scale, const float* in_shift, float in_slope,
+                                  const float* residual, int r_ldc, const float* out_scale, double* stats,
+                                  int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, void* stream) {
+  if (!x || !wpk16 || !y || N <= 0 || Cin <= 0 || Cout <= 0) return CWF_E_BADARG;
+  if ((Cin & 3) || (x_ldc & 3) || x_ldc < Cin || y_ldc < Cout) return CWF_E_ALIGN;
+  if (((uintptr_t)x & 15) || ((uintptr_t)wpk16 & 15)) return CWF_E_ALIGN;
+  if (in_scale && !in_shift) return CWF_E_BADARG;
+  ConvArgsB a;
+  int cd[3] = {Do, Ho, Wo}; int ncls = 1;
+  if (op == CWF_CONVT2) { cd[0] = Di; cd[1] = Hi; cd[2] = Wi; ncls = 8; }
+  if (op == CWF_CONV3_S2_DGRAD) { cd[0] = (Do + 1) / 2; cd[1] = (Ho + 1) / 2; cd[2] = (Wo + 1) / 2; ncls = 8; }
+  const TileCfg c = choose_cfg(op, cd, ncls, N, cdiv(Cout, 16));
+  int rc = cwf_build_geom(a.g, op, N, Di, Hi, Wi, Cin, x_ldc, Do, Ho, Wo, Cout, y_ldc, c.MT * c.WM);
+  if (rc) return rc;
+  a.x = x; a.wpk = reinterpret_cast<const uint4*>(wpk16); a.bias = bias; a.y = y; a.in_scale = in_scale; a.in_shift = in_shift;
+  a.in_slope = in_slope; a.residual = residual; a.r_ldc = r_ldc; a.out_scale = out_scale; a.stats = stats;
+  hipStream_t st = cwf_stream(stream);
+#define CWF_CFG(mt, nt, wm) if (c.MT == mt && c.NT == nt && c.WM == wm) return x3 ? launch_cfg<mt, nt, wm, true>(a, st) : launch_cfg<mt, nt, wm, false>(a, st);
+  CWF_CFG(4, 4, 1) CWF_CFG(2, 4, 2) CWF_CFG(2, 4, 4) CWF_CFG(4, 2, 4) CWF_CFG(4, 1, 4)
+  CWF_CFG(1, 4, 4) CWF_CFG(1, 2, 4) CWF_CFG(1, 2, 2) CWF_CFG(1, 1, 4)
+#undef CWF_CFG
+  return CWF_E_BADARG;
+}

@@ -221,10 +221,13 @@ int cwf_build_geom(ConvGeom& g, int op, int N, int Di, int Hi, int Wi, int Cin, 
   g.ID = (g.TD - 1) * g.is + (hi[0] - g.lo[0] + 1);
   g.IH = (g.TH - 1) * g.is + (hi[1] - g.lo[1] + 1);
   g.IW = (16 - 1) * g.is + (hi[2] - g.lo[2] + 1);
-  int wb = 0, md = 0, mh = 0, mw = 0;
+  int wb = 0, wb16 = 0, md = 0, mh = 0, mw = 0;
+  for (int c = 0; c < 8; ++c) g.cls_wbase16[c] = 0;
   for (int c = 0; c < g.ncls; ++c) {
     g.cls_wbase[c] = wb;
     wb += g.nchunks * g.cls_ntaps[c] * g.ntiles;
+    g.cls_wbase16[c] = wb16;
+    wb16 += g.nchunks * ((g.cls_ntaps[c] + 1) / 2) * g.ntiles;
     for (int t = 0; t < g.cls_ntaps[c]; ++t)
       g.tapofs[(g.ncls > 1 ? c * 8 : 0) + t] =
           ((tapd[c][t][0] - g.lo[0]) * g.IH + (tapd[c][t][1] - g.lo[1])) * g.IW + (tapd[c][t][2] - g.lo[2]);

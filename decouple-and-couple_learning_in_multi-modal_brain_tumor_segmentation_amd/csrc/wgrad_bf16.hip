@@ -1,0 +1,261 @@
+// K1w (split-bf16 form) -- weight/bias gradient of the conv family on v_mfma_f32_16x16x32_bf16.
+//
+//   dW[tap][ci][co] = sum_vox xa[vox + tap][ci] * dy[vox][co]     M = ci (16), N = co (16), K = voxels (32 per MFMA)
+// Both operands are K-major for this product (the voxel index is the summation index) but live voxel-major in LDS
+// ([voxel][16 ch] bf16, written coalesced from NDHWC HBM), so both fragments are fetched with the CDNA4 transposing LDS
+// read ds_read_b64_tr_b16: per 16-lane group it takes a 4-voxel x 16-channel block and hands lane i channel i of the
+// 4 voxels -- two reads give the 8 consecutive-k bf16 values of a 16x16x32 operand, no shuffles, no second LDS image.
+// (EXEC is all ones at every such read: all branches around them are wave-uniform.)
+// X3 = true: x = xh + xl, dy = dh + dl -> xh.dh + xh.dl + xl.dh (fp32 accumulate);  X3 = false: xh.dh only.
+// Work split, persistent tile walk, partial-slab layout and the reduce step are those of wgrad_mfma.hip.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+struct WgArgsB {
+  ConvGeom g;
+  const float* x; const float* in_scale; const float* in_shift; float in_slope;
+  const float* dy; int dy_ldc; float* partial;
+  int ngroups, tiles_per_split, total_tiles;
+  int64_t slab_floats;
+  int cls_slab_base[8];
+};
+
+__device__ __forceinline__ unsigned pack_bf16w(float a, float b) {
+  const __bf16 x = (__bf16)a, y = (__bf16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+__device__ __forceinline__ float bf16_roundw(float a) { return (float)(__bf16)a; }
+
+// two transposed reads -> one 8-element K fragment.  p0 / p1: this lane's block-row addresses (bf16 element pointers)
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned short* p0, const unsigned short* p1) {
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int TPW, int NTW, bool TAPSPLIT, bool X3>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgsB a) {
+  constexpr int CG = NTW;
+  constexpr int CGW = CG * 16;
+  extern __shared__ float4 lds4[];
+  const ConvGeom& g = a.g;
+  const int nvox_in = g.ID * g.IH * g.IW;
+  const int MV = g.TD * g.TH * 16;
+  unsigned short* xh = reinterpret_cast<unsigned short*>(lds4);
+  unsigned short* xl = xh + nvox_in * 16;
+  unsigned short* dh = xl + (X3 ? nvox_in * 16 : 0);
+  unsigned short* dl = dh + MV * CGW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = lane >> 4;
+  const int bq = (lane & 15) >> 2, bp = lane & 3;        // transposed-read block row / column quad supplied by this lane
+  const int split = blockIdx.x;
+  const int chunk = blockIdx.y / a.ngroups, grp = blockIdx.y % a.ngroups;
+  const int cls = blockIdx.z;
+  const int Dc = g.cls_dims[cls][0], Hc = g.cls_dims[cls][1], Wc = g.cls_dims[cls][2];
+  const int ntaps = g.cls_ntaps[cls];
+  const int* tapofs = g.tapofs + (g.ncls > 1 ? cls * 8 : 0);
+  const int co0 = grp * CGW;
+
+  f32x4 acc[TPW][NTW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int tiles_sp = g.tiles_d * g.tiles_h * g.tiles_w;
+  const int t_begin = split * a.tiles_per_split;
+  const int t_end = min(a.total_tiles, t_begin + a.tiles_per_split);
+  const bool vec_dy = (a.dy_ldc & 3) == 0 && (((uintptr_t)a.dy) & 15) == 0;
+  const int of0 = g.cls_ooff[cls][0], of1 = g.cls_ooff[cls][1], of2 = g.cls_ooff[cls][2];
+
+  // ones operand for the bias row: bf16 1.0 = 0x3F80
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int n = tile / tiles_sp; int rem = tile % tiles_sp;
+    const int tile_w = rem % g.tiles_w; rem /= g.tiles_w;
+    const int tile_h = rem % g.tiles_h; const int tile_d = rem / g.tiles_h;
+    const int od0 = tile_d * g.TD, oh0 = tile_h * g.TH, ow0 = tile_w * 16;
+    if (od0 >= Dc || oh0 >= Hc || ow0 >= Wc) continue;
+    __syncthreads();
+    // ---- x tile (activated) as bf16 hi/lo
+    {
+      const int q = tid & 3;
+      const int c = chunk * 16 + q * 4;
+      const bool cval = c < g.Cin;
+      const bool has_norm = a.in_scale != nullptr;
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_norm && cval) {
+        sc = *reinterpret_cast<const float4*>(a.in_scale + (int64_t)n * g.Cin + c);
+        sh = *reinterpret_cast<const float4*>(a.in_shift + (int64_t)n * g.Cin + c);
+      }
+      const int id0 = od0 * g.is + g.lo[0], ih0 = oh0 * g.is + g.lo[1], iw0 = ow0 * g.is + g.lo[2];
+      for (int v = tid >> 2; v < nvox_in; v += 64) {
+        const int iw = v % g.IW; const int t2 = v / g.IW;
+        const int ih = t2 % g.IH; const int idd = t2 / g.IH;
+        const int gd = id0 + idd, gh = ih0 + ih, gw = iw0 + iw;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cval && gd >= 0 && gd < g.Di && gh >= 0 && gh < g.Hi && gw >= 0 && gw < g.Wi) {
+          val = *reinterpret_cast<const float4*>(a.x + ((((int64_t)n * g.Di + gd) * g.Hi + gh) * g.Wi + gw) * g.x_ldc + c);
+          if (has_norm || a.in_slope != 1.f) {
+            val.x = cwf_act(val.x * sc.x + sh.x, a.in_slope); val.y = cwf_act(val.y * sc.y + sh.y, a.in_slope);
+            val.z = cwf_act(val.z * sc.z + sh.z, a.in_slope); val.w = cwf_act(val.w * sc.w + sh.w, a.in_slope);
+          }
+        }
+        uint2 h; h.x = pack_bf16w(val.x, val.y); h.y = pack_bf16w(val.z, val.w);
+        *reinterpret_cast<uint2*>(xh + v * 16 + q * 4) = h;
+        if (X3) {
+          uint2 l;
+          l.x = pack_bf16w(val.x - bf16_roundw(val.x), val.y - bf16_roundw(val.y));
+          l.y = pack_bf16w(val.z - bf16_roundw(val.z), val.w - bf16_roundw(val.w));
+          *reinterpret_cast<uint2*>(xl + v * 16 + q * 4) = l;
+        }
+      }
+    }
+    // ---- dy tile [MV][CGW] as bf16 hi/lo
+    for (int e = tid; e < MV * (CGW / 4); e += 256) {
+      const int vox = e / (CGW / 4), cq = e % (CGW / 4);
+      const int tw = vox & 15, mt = vox >> 4;
+      const int od = od0 + mt / g.TH, oh = oh0 + mt % g.TH, ow = ow0 + tw;
+      const int co = co0 + cq * 4;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (od < Dc && oh < Hc && ow < Wc && co < g.Cout) {
+        const int64_t gv = (((int64_t)n * g.Do + (od * g.os + of0)) * g.Ho + (oh * g.os + of1)) * g.Wo + (ow * g.os + of2);
+        const float* p = a.dy + gv * a.dy_ldc + co;
+        if (vec_dy && co + 3 < g.y_ldc) {
+          val = *reinterpret_cast<const float4*>(p);
+          if (co + 1 >= g.Cout) val.y = 0.f;
+          if (co + 2 >= g.Cout) val.z = 0.f;
+          if (co + 3 >= g.Cout) val.w = 0.f;
+        } else {
+          val.x = p[0];
+          if (co + 1 < g.Cout) val.y = p[1];
+          if (co + 2 < g.Cout) val.z = p[2];
+          if (co + 3 < g.Cout) val.w = p[3];
+        }
+      }
+      uint2 h; h.x = pack_bf16w(val.x, val.y); h.y = pack_bf16w(val.z, val.w);
+      *reinterpret_cast<uint2*>(dh + vox * CGW + cq * 4) = h;
+      if (X3) {
+        uint2 l;
+        l.x = pack_bf16w(val.x - bf16_roundw(val.x), val.y - bf16_roundw(val.y));
+        l.y = pack_bf16w(val.z - bf16_roundw(val.z), val.w - bf16_roundw(val.w));
+        *reinterpret_cast<uint2*>(dl + vox * CGW + cq * 4) = l;
+      }
+    }
+    __syncthreads();
+
+    // ---- K loop: one step = 32 voxels = M-tiles (2ks, 2ks+1); lane group kq -> M-tile 2ks + (kq>>1), voxels 8(kq&1)..+7
+    const int nks = (g.TD * g.TH) >> 1;
+#pragma unroll 1
+    for (int ks = 0; ks < nks; ++ks) {
+      if (!TAPSPLIT && (ks & 3) != wave) continue;           // 1-tap ops: waves split the voxels (wave-uniform)
+      const int mt = 2 * ks + (kq >> 1);
+      const int tw0 = (kq & 1) * 8 + bq;                     // this lane's block row (first of the two 4-voxel blocks)
+      const int vin = ((((mt / g.TH) * g.is) * g.IH + (mt % g.TH) * g.is) * g.IW + tw0 * g.is) * 16 + bp * 4;
+      const int vin4 = vin + 4 * g.is * 16;
+      const int vout = (mt * 16 + tw0) * CGW + bp * 4;
+      const int vout4 = vout + 4 * CGW;
+      bf16x8 bh[NTW], bl[NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        bh[j] = tr_frag(dh + vout + j * 16, dh + vout4 + j * 16);
+        if (X3) bl[j] = tr_frag(dl + vout + j * 16, dl + vout4 + j * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        const int t = TAPSPLIT ? wave + 4 * i : i;
+        if (t > ntaps) continue;                             // wave-uniform
+        if (t == ntaps) {                                    // bias row: ones . dy
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bh[j], acc[i][j], 0, 0, 0);
+            if (X3) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bl[j], acc[i][j], 0, 0, 0);
+          }
+        } else {
+          const int to = tapofs[t] * 16;
+          const bf16x8 ah = tr_frag(xh + vin + to, xh + vin4 + to);
+          bf16x8 al;
+          if (X3) al = tr_frag(xl + vin + to, xl + vin4 + to);
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+            if (X3) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  float4* out = reinterpret_cast<float4*>(a.partial + (int64_t)(TAPSPLIT ? split : split * 4 + wave) * a.slab_floats);
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int t = TAPSPLIT ? wave + 4 * i : i;
+    if (t > ntaps) continue;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int64_t blk = (int64_t)a.cls_slab_base[cls] + (((int64_t)chunk * a.ngroups + grp) * (ntaps + 1) + t) * CG + j;
+      out[blk * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+  }
+}
+
+// plan: identical decisions to wgrad_mfma.hip (the Python side sizes the workspace through cwf_wgrad_nsplit / _slab_floats)
+extern "C" int cwf_wgrad_nsplit(int op, int N, int Do, int Ho, int Wo, int Cin, int Cout);
+extern "C" int64_t cwf_wgrad_slab_floats(int op, int Cin, int Cout);
+
+extern "C" int cwf_wgrad_mfma_bf16(int op, int x3, const float* x, int x_ldc, const float* in_scale, const float* in_shift, float in_slope,
+                                   const float* dy, int dy_ldc, float* partial,
+                                   int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, void* stream) {
+  if (!x || !dy || !partial || N <= 0) return CWF_E_BADARG;
+  if ((Cin & 3) || (x_ldc & 3) || ((uintptr_t)x & 15) || ((uintptr_t)partial & 15)) return CWF_E_ALIGN;
+  if (in_scale && !in_shift) return CWF_E_BADARG;
+  if (!(op == CWF_CONV3_S1 || op == CWF_CONV3_S2 || op == CWF_CONV1 || op == CWF_CONVT2)) return CWF_E_BADARG;
+  const bool tapsplit = (op == CWF_CONV3_S1 || op == CWF_CONV3_S2);
+  const int MTOT = (op == CWF_CONV3_S2) ? 4 : 16;
+  const int nt_all = cdiv(Cout, 16);
+  const int CG = tapsplit ? (nt_all == 1 ? 1 : 2) : (nt_all == 1 ? 1 : (nt_all == 2 ? 2 : 4));
+  WgArgsB a;
+  int rc = cwf_build_geom(a.g, op, N, Di, Hi, Wi, Cin, x_ldc, Do, Ho, Wo, Cout, dy_ldc, MTOT);
+  if (rc) return rc;
+  const int nchunks = a.g.nchunks, ncls = a.g.ncls, ngroups = cdiv(a.g.ntiles, CG);
+  int64_t blocks = 0;
+  for (int c = 0; c < 8; ++c) { a.cls_slab_base[c] = (int)blocks; if (c < ncls) blocks += (int64_t)nchunks * ngroups * (a.g.cls_ntaps[c] + 1) * CG; }
+  const int total = N * a.g.tiles_d * a.g.tiles_h * a.g.tiles_w;
+  const int nblk = nchunks * ngroups * ncls;
+  int want = 512 / nblk; if (want < 1) want = 1; if (want > total) want = total;
+  const int tps = cdiv(total, want);
+  const int wg_splits = cdiv(total, tps);
+  // must agree with wgrad_mfma.hip's plan (the workspace was sized from it)
+  if ((tapsplit ? wg_splits : wg_splits * 4) != cwf_wgrad_nsplit(op, N, Do, Ho, Wo, Cin, Cout) || blocks * 256 != cwf_wgrad_slab_floats(op, Cin, Cout))
+    return CWF_E_BADARG;
+  a.x = x; a.in_scale = in_scale; a.in_shift = in_shift; a.in_slope = in_slope; a.dy = dy; a.dy_ldc = dy_ldc; a.partial = partial;
+  a.ngroups = ngroups; a.tiles_per_split = tps; a.total_tiles = total; a.slab_floats = blocks * 256;
+  const size_t nvox_in = (size_t)a.g.ID * a.g.IH * a.g.IW;
+  const size_t mv = (size_t)a.g.TD * a.g.TH * 16;
+  const size_t lds = (nvox_in * 16 + mv * CG * 16) * sizeof(unsigned short) * (x3 ? 2 : 1);
+  if (lds > 160 * 1024) return CWF_E_TOOLARGE;
+  dim3 grid(wg_splits, nchunks * ngroups, ncls);
+  hipStream_t st = cwf_stream(stream);
+#define CWF_WG(tpw, ntw, ts, xx) do { static bool attr = false; \
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<tpw, ntw, ts, xx>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+    hipLaunchKernelGGL((wgrad_bf16_kernel<tpw, ntw, ts, xx>), grid, dim3(256), lds, st, a); } while (0)
+#define CWF_WGX(tpw, ntw, ts) do { if (x3) CWF_WG(tpw, ntw, ts, true); else CWF_WG(tpw, ntw, ts, false); } while (0)
+  if (tapsplit) { if (CG == 1) CWF_WGX(7, 1, true); else CWF_WGX(7, 2, true); }
+  else { if (CG == 1) CWF_WGX(2, 1, false); else if (CG == 2) CWF_WGX(2, 2, false); else CWF_WGX(2, 4, false); }
+#undef CWF_WGX
+#undef CWF_WG
+  CWF_LAUNCH_CHECK();
+  return 0;
+}

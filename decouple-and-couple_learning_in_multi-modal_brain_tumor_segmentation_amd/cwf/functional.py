@@ -14,45 +14,57 @@ import numpy as np
 import torch
 
 from . import packing as pk
-from .kernels import backend
+from .kernels import backend, precision
 
 
 # ======================================================================================================
 # per-layer conv description + once-per-step weight packing
 # ======================================================================================================
 class ConvSpec:
-    """Static description of one conv layer: op code, channel counts and the index maps (device tensors)."""
+    """Static description of one conv layer: op code, channel counts and the index maps (device tensors) for the
+    fp32 and the split-bf16 kernel forms."""
 
     def __init__(self, op, cin, cout):
         self.op, self.cin, self.cout = op, cin, cout
         self.cout_alloc = (cout + 3) // 4 * 4
         self.np_fwd = pk.fwd_map(op, cin, cout)
         self.np_dgrad = pk.dgrad_map(op, cin, cout, self.cout_alloc)
+        self.np_fwd16 = pk.fwd_map16(op, cin, cout)
+        self.np_dgrad16 = pk.dgrad_map16(op, cin, cout, self.cout_alloc)
         self.np_inv, self.has_bias_map, self.slab = pk.wgrad_inverse_map(op, cin, cout)
         self.dev = None
-        self.fwd_map = self.dgrad_map = self.inv_map = None
-        self.wpk_f = self.wpk_d = None
+        self.fwd_map = self.dgrad_map = self.inv_map = self.fwd_map16 = self.dgrad_map16 = None
+        self.wpk_f = self.wpk_d = self.wpk16_f = self.wpk16_d = None
 
     def to(self, device):
         if self.dev == device:
             return self
         t = lambda a: None if a is None else torch.from_numpy(a).to(device)
         self.fwd_map, self.dgrad_map, self.inv_map = t(self.np_fwd), t(self.np_dgrad), t(self.np_inv)
+        self.fwd_map16, self.dgrad_map16 = t(self.np_fwd16), t(self.np_dgrad16)
         self.wpk_f = torch.zeros(self.np_fwd.size, dtype=torch.float32, device=device)
         self.wpk_d = torch.zeros(self.np_dgrad.size, dtype=torch.float32, device=device)
+        # split-bf16: hi and lo images side by side = 2 bf16 per map entry = one float32 slot per entry
+        self.wpk16_f = torch.zeros(self.np_fwd16.size, dtype=torch.float32, device=device)
+        self.wpk16_d = torch.zeros(self.np_dgrad16.size, dtype=torch.float32, device=device)
         self.dev = device
         return self
+
+    def packed(self, dgrad=False):
+        """The packed weight buffer the active kernel form consumes."""
+        if precision() == "fp32":
+            return self.wpk_d if dgrad else self.wpk_f
+        return self.wpk16_d if dgrad else self.wpk16_f
 
 
 class WeightPacker:
     """Packs every conv weight into the MFMA B-operand layouts (forward + data-gradient forms) with ONE launch
-    per step (cwf_gather_batched over a device-resident descriptor table)."""
+    per step (cwf_gather_batched / cwf_gather_split_bf16 over a device-resident descriptor table)."""
 
     def __init__(self):
         self.items = []          # (spec, weight Parameter)
         self._key = None
-        self._table = None
-        self._max_n = 0
+        self._tables = None
 
     def add(self, spec, weight):
         self.items.append((spec, weight))
@@ -63,16 +75,20 @@ class WeightPacker:
         dev = self.items[0][1].device
         key = (dev, tuple(w.data_ptr() for _, w in self.items))
         if key != self._key:
-            rows = []
+            r32, r16 = [], []
             for spec, w in self.items:
                 spec.to(dev)
                 assert w.is_contiguous()
-                rows.append([w.data_ptr(), spec.wpk_f.data_ptr(), spec.fwd_map.data_ptr(), spec.fwd_map.numel()])
-                rows.append([w.data_ptr(), spec.wpk_d.data_ptr(), spec.dgrad_map.data_ptr(), spec.dgrad_map.numel()])
-            self._table = torch.tensor(rows, dtype=torch.int64).to(dev)
-            self._max_n = max(r[3] for r in rows)
+                r32.append([w.data_ptr(), spec.wpk_f.data_ptr(), spec.fwd_map.data_ptr(), spec.fwd_map.numel()])
+                r32.append([w.data_ptr(), spec.wpk_d.data_ptr(), spec.dgrad_map.data_ptr(), spec.dgrad_map.numel()])
+                r16.append([w.data_ptr(), spec.wpk16_f.data_ptr(), spec.fwd_map16.data_ptr(), spec.fwd_map16.numel()])
+                r16.append([w.data_ptr(), spec.wpk16_d.data_ptr(), spec.dgrad_map16.data_ptr(), spec.dgrad_map16.numel()])
+            self._tables = {"fp32": (torch.tensor(r32, dtype=torch.int64).to(dev), max(r[3] for r in r32)),
+                            "bf16": (torch.tensor(r16, dtype=torch.int64).to(dev), max(r[3] for r in r16))}
             self._key = key
-        backend().gather_batched(self._table, self._table.shape[0], self._max_n)
+        kind = "fp32" if precision() == "fp32" else "bf16"
+        table, max_n = self._tables[kind]
+        backend().gather_batched(table, table.shape[0], max_n, split_bf16=(kind == "bf16"))
 
 
 # ======================================================================================================
@@ -84,7 +100,7 @@ class _ConvFn(torch.autograd.Function):
         K = backend()
         n = x.shape[0]
         stats = K.new_stats(n, spec.cout, x.device) if want_stats else None
-        y = K.conv(spec.op, x, spec.wpk_f, b, spec.cout, in_scale, in_shift, slope, residual, out_scale, stats,
+        y = K.conv(spec.op, x, spec.packed(False), b, spec.cout, in_scale, in_shift, slope, residual, out_scale, stats,
                    w_ref=w, out_channels_alloc=spec.cout_alloc)
         ctx.spec, ctx.slope = spec, slope
         ctx.has_res = residual is not None
@@ -112,7 +128,7 @@ class _ConvFn(torch.autograd.Function):
                 db = K.in_stats(dy)[:, :, 0].sum(0).float()
         if ctx.needs_input_grad[0]:
             dxa = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-            K.conv(pk.dgrad_op(spec.op), dy, spec.wpk_d, None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op)
+            K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op)
             if in_scale is not None:
                 dx = K.in_bwd(dxa, x, in_scale, in_shift, ctx.slope)
             else:

@@ -35,6 +35,25 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+# Arithmetic of the conv family (forward, data gradient, weight gradient).  Activations / weights are fp32 in HBM in
+# every mode; the mode selects the MFMA operand form:
+#   "fp32"   v_mfma_f32_16x16x4_f32, exact f32 (the parity reference mode)
+#   "bf16x3" split-bf16: hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16, fp32 accumulate (~2^-16 per product)
+#   "bf16"   single bf16 product (2^-9 per product)
+_PRECISION = "fp32"
+
+
+def set_precision(mode: str):
+    global _PRECISION
+    if mode not in ("fp32", "bf16x3", "bf16"):
+        raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16'")
+    _PRECISION = mode
+
+
+def precision() -> str:
+    return _PRECISION
+
+
 class HipBackend:
     name = "hip"
 
@@ -64,7 +83,7 @@ class HipBackend:
 
     # ------------------------------------------------------------------ K1
     def conv(self, op, x, wpk, bias, cout, in_scale=None, in_shift=None, slope=1.0, residual=None, out_scale=None,
-             stats=None, out=None, w_ref=None, out_channels_alloc=None, fwd_op=None):
+             stats=None, out=None, w_ref=None, out_channels_alloc=None, fwd_op=None, prec=None):
         """Returns the output buffer.  With out_channels_alloc > cout the buffer has zero-filled padding channels
         (2-channel heads live in 4-channel tensors so that every later kernel sees 16-byte voxel rows).
         w_ref / fwd_op are ignored here (the test emulation uses them instead of the packed weights)."""
@@ -83,12 +102,18 @@ class HipBackend:
         r_ldc = 0
         if residual is not None:
             residual, r_ldc = cl(residual)
-        self._call("cwf_conv_mfma", op, x.data_ptr(), x_ldc, wpk.data_ptr(), _p(bias), y.data_ptr(), y_ldc,
-                   _p(in_scale), _p(in_shift), float(slope), _p(residual), r_ldc, _p(out_scale), _p(stats),
-                   n, di, hi, wi, cin, do, ho, wo, cout, self._stream())
+        mode = prec or _PRECISION
+        if mode == "fp32":
+            self._call("cwf_conv_mfma", op, x.data_ptr(), x_ldc, wpk.data_ptr(), _p(bias), y.data_ptr(), y_ldc,
+                       _p(in_scale), _p(in_shift), float(slope), _p(residual), r_ldc, _p(out_scale), _p(stats),
+                       n, di, hi, wi, cin, do, ho, wo, cout, self._stream())
+        else:
+            self._call("cwf_conv_mfma_bf16", op, 1 if mode == "bf16x3" else 0, x.data_ptr(), x_ldc, wpk.data_ptr(), _p(bias),
+                       y.data_ptr(), y_ldc, _p(in_scale), _p(in_shift), float(slope), _p(residual), r_ldc, _p(out_scale),
+                       _p(stats), n, di, hi, wi, cin, do, ho, wo, cout, self._stream())
         return y
 
-    def wgrad(self, op, x, in_scale, in_shift, slope, dy, cout, inv_map, has_bias_map, w_numel, w_ref_shape=None):
+    def wgrad(self, op, x, in_scale, in_shift, slope, dy, cout, inv_map, has_bias_map, w_numel, w_ref_shape=None, prec=None):
         """returns (dW flat [w_numel], db [cout] or None)"""
         x, x_ldc = cl(x)
         dy, dy_ldc = cl(dy)
@@ -99,15 +124,20 @@ class HipBackend:
         if nsplit <= 0 or slab <= 0 or slab != inv_map.numel():
             raise _lib.CwfError("cwf_wgrad plan failed (%d, %d, %d)" % (nsplit, slab, inv_map.numel()))
         part = self.workspace("wgrad", nsplit * slab, x.device)
-        self._call("cwf_wgrad_mfma", op, x.data_ptr(), x_ldc, _p(in_scale), _p(in_shift), float(slope),
-                   dy.data_ptr(), dy_ldc, part.data_ptr(), n, di, hi, wi, cin, do, ho, wo, cout, self._stream())
+        mode = prec or _PRECISION
+        if mode == "fp32":
+            self._call("cwf_wgrad_mfma", op, x.data_ptr(), x_ldc, _p(in_scale), _p(in_shift), float(slope),
+                       dy.data_ptr(), dy_ldc, part.data_ptr(), n, di, hi, wi, cin, do, ho, wo, cout, self._stream())
+        else:
+            self._call("cwf_wgrad_mfma_bf16", op, 1 if mode == "bf16x3" else 0, x.data_ptr(), x_ldc, _p(in_scale), _p(in_shift),
+                       float(slope), dy.data_ptr(), dy_ldc, part.data_ptr(), n, di, hi, wi, cin, do, ho, wo, cout, self._stream())
         dw = torch.empty(w_numel, dtype=_f32, device=x.device)
         db = torch.empty(cout, dtype=_f32, device=x.device) if has_bias_map else None
         self._call("cwf_wgrad_reduce", part.data_ptr(), nsplit, slab, inv_map.data_ptr(), dw.data_ptr(), _p(db), self._stream())
         return dw, db
 
-    def gather_batched(self, table, nlayers, max_n):
-        self._call("cwf_gather_batched", table.data_ptr(), nlayers, max_n, self._stream())
+    def gather_batched(self, table, nlayers, max_n, split_bf16=False):
+        self._call("cwf_gather_split_bf16" if split_bf16 else "cwf_gather_batched", table.data_ptr(), nlayers, max_n, self._stream())
 
     # ------------------------------------------------------------------ K3
     def new_stats(self, n, c, device):

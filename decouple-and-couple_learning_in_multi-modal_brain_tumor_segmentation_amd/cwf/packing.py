@@ -151,3 +151,55 @@ def wgrad_inverse_map(op, cin, cout):
     if b_map is not None:
         inv[b_map] = -2 - np.arange(b_map.size, dtype=np.int32)
     return inv, b_map is not None, slab
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# split-bf16 packing (csrc/conv_bf16.hip): [class][ci_chunk16][tap pair][co_tile16][lane64][8]  (one int32 per bf16 of the
+# hi image; the kernel writes hi and lo side by side).  lane = kq*16 + r: tap = 2*pair + (kq>>1), ci = chunk*16 + (kq&1)*8 + j,
+# co = tile*16 + r.
+# ----------------------------------------------------------------------------------------------------------------
+def _pack_map16(ncls_taps, cin, cout, src_index):
+    nch, nt = _cdiv(cin, 16), _cdiv(cout, 16)
+    ci = np.arange(nch * 16).reshape(-1, 1)
+    co = np.arange(nt * 16).reshape(1, -1)
+    valid = (ci < cin) & (co < cout)
+    blocks = []
+    for cls, taps in enumerate(ncls_taps):
+        npairs = (len(taps) + 1) // 2
+        per_cls = np.full((nch, npairs, nt, 4, 16, 8), -1, dtype=np.int64)       # chunk, pair, tile, kq, r, j
+        for t, tap in enumerate(taps):
+            idx = np.where(valid, src_index(cls, tap, np.minimum(ci, cin - 1), np.minimum(co, cout - 1)), -1)   # [nch*16, nt*16]
+            a = idx.reshape(nch, 2, 8, nt, 16)             # chunk, half (kq&1), j, tile, r
+            a = a.transpose(0, 3, 1, 4, 2)                  # chunk, tile, half, r, j
+            for half in range(2):
+                per_cls[:, t // 2, :, (t % 2) * 2 + half] = a[:, :, half]
+        blocks.append(per_cls.reshape(-1))
+    return np.concatenate(blocks).astype(np.int32)
+
+
+def fwd_map16(op, cin, cout):
+    if op in (CONV3_S1, CONV3_S2):
+        return _pack_map16([_taps3()], cin, cout, lambda c, k, ci, co: ((co * cin + ci) * 3 + k[0]) * 9 + k[1] * 3 + k[2])
+    if op == CONV1:
+        return _pack_map16([[None]], cin, cout, lambda c, k, ci, co: co * cin + ci)
+    if op == CONVT2:
+        return _pack_map16([[c] for c in range(8)], cin, cout, lambda c, k, ci, co: (ci * cout + co) * 8 + k)
+    raise ValueError(op)
+
+
+def dgrad_map16(op, cin, cout, cout_alloc=None):
+    ca = cout_alloc or cout
+
+    def guard(f):
+        return lambda c, k, ci, co: np.where(ci < cout, f(c, k, np.minimum(ci, cout - 1), co), -1)
+    if op == CONV3_S1:
+        return _pack_map16([_taps3()], ca, cin,
+                           guard(lambda c, k, ci, co: ((ci * cin + co) * 3 + (2 - k[0])) * 9 + (2 - k[1]) * 3 + (2 - k[2])))
+    if op == CONV1:
+        return _pack_map16([[None]], ca, cin, guard(lambda c, k, ci, co: ci * cin + co))
+    if op == CONV3_S2:
+        return _pack_map16(_s2_dgrad_classes(), ca, cin,
+                           guard(lambda c, k, ci, co: ((ci * cin + co) * 3 + k[0]) * 9 + k[1] * 3 + k[2]))
+    if op == CONVT2:
+        return _pack_map16([list(range(8))], ca, cin, guard(lambda c, k, ci, co: (co * cout + ci) * 8 + k))
+    raise ValueError(op)

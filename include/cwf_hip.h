@@ -81,9 +81,30 @@ int cwf_wgrad_mfma(int op,
 int cwf_wgrad_reduce(const float* partial, int nsplit, int64_t slab_floats,
                      const int32_t* inv_map, float* dW, float* db, void* stream);
 
+struct cwf_gather_desc { const float* src; float* dst; const int32_t* map; int64_t n; };
+
+/* Split-bf16 forms of K1 (same geometry, epilogues and argument meaning; activations and weights stay fp32 in HBM):
+ * MFMA operands are bf16 on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.
+ *   x3 != 0 ("bf16x3"): v = hi + lo per operand, products hi.hi + hi.lo + lo.hi  (~2^-16 relative per product, 3 MFMAs)
+ *   x3 == 0 ("bf16")  : hi.hi only                                                 (2^-9 relative per product, 1 MFMA)
+ * wpk16: weights packed by cwf_gather_split_bf16 ([class][ci_chunk16][tap pair][co_tile16][lane64][hi 8 | lo 8] bf16);
+ * its index map has one int32 per bf16 element of the hi image (8 per lane), see cwf/packing.py.                       */
+int cwf_conv_mfma_bf16(int op, int x3,
+                       const float* x, int x_ldc, const void* wpk16, const float* bias,
+                       float* y, int y_ldc,
+                       const float* in_scale, const float* in_shift, float in_slope,
+                       const float* residual, int r_ldc, const float* out_scale, double* stats,
+                       int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+                       void* stream);
+int cwf_wgrad_mfma_bf16(int op, int x3,
+                        const float* x, int x_ldc, const float* in_scale, const float* in_shift, float in_slope,
+                        const float* dy, int dy_ldc, float* partial,
+                        int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+                        void* stream);
+int cwf_gather_split_bf16(const struct cwf_gather_desc* table, int nlayers, int64_t max_n, void* stream);
+
 /* dst[i] = map[i] >= 0 ? src[map[i]] : 0 for a table of `nlayers` descriptors resident in device memory
  * (struct cwf_gather_desc).  Used once per step to pack every layer's weights for K1.               */
-struct cwf_gather_desc { const float* src; float* dst; const int32_t* map; int64_t n; };
 int cwf_gather_batched(const struct cwf_gather_desc* table, int nlayers, int64_t max_n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -62,7 +62,7 @@ class EmulBackend:
 
     # ------------------------------------------------------------------ K1
     def conv(self, op, x, wpk, bias, cout, in_scale=None, in_shift=None, slope=1.0, residual=None, out_scale=None,
-             stats=None, out=None, w_ref=None, out_channels_alloc=None, fwd_op=None):
+             stats=None, out=None, w_ref=None, out_channels_alloc=None, fwd_op=None, prec=None):
         """cwf_conv_mfma: F.conv3d / F.conv_transpose3d on act(IN(x)) (+bias, +residual, *out_scale) or, for the
         data-gradient forms (fwd_op given), the adjoint of the forward conv w.r.t. its (activated) input."""
         assert w_ref is not None
@@ -90,7 +90,7 @@ class EmulBackend:
         out.copy_(g)
         return out
 
-    def wgrad(self, op, x, in_scale, in_shift, slope, dy, cout, inv_map, has_bias_map, w_numel, w_ref_shape=None):
+    def wgrad(self, op, x, in_scale, in_shift, slope, dy, cout, inv_map, has_bias_map, w_numel, w_ref_shape=None, prec=None):
         """cwf_wgrad_mfma + cwf_wgrad_reduce: weight / bias halves of aten::convolution_backward on act(IN(x))."""
         xa = _prologue(x, in_scale, in_shift, slope).detach()
         w = torch.zeros(w_ref_shape, dtype=torch.float32, requires_grad=True)
@@ -100,7 +100,7 @@ class EmulBackend:
             gw, gb = torch.autograd.grad(y, (w, b), dy.contiguous())
         return gw.reshape(-1), (gb if has_bias_map else None)
 
-    def gather_batched(self, table, nlayers, max_n):
+    def gather_batched(self, table, nlayers, max_n, split_bf16=False):
         pass    # packed buffers are unused by the emulation
 
     # ------------------------------------------------------------------ K3

@@ -28,13 +28,21 @@ def close(got, ref, rtol=2e-5, atol=None, what=""):
     assert err <= atol + rtol * float(ref.abs().max()), (what, err, float(ref.abs().max()))
 
 
-def _packed(spec, w):
-    from cwf import functional as CF
-    spec.to(torch.device(DEV))
-    wd = w.to(DEV).contiguous().reshape(-1)
-    spec.wpk_f.copy_(torch.where(spec.fwd_map >= 0, wd[spec.fwd_map.clamp_min(0).long()], torch.zeros((), device=DEV)))
-    spec.wpk_d.copy_(torch.where(spec.dgrad_map >= 0, wd[spec.dgrad_map.clamp_min(0).long()], torch.zeros((), device=DEV)))
+def _packed(spec, w, prec="fp32"):
+    """Pack through the product path (WeightPacker -> cwf_gather_batched / cwf_gather_split_bf16)."""
+    from cwf import functional as CF, kernels
+    packer = CF.WeightPacker()
+    packer.add(spec, torch.nn.Parameter(w.to(DEV).contiguous()))
+    kernels.set_precision(prec)
+    try:
+        packer.refresh()
+    finally:
+        kernels.set_precision("fp32")
+    spec._keepalive = packer
     return spec
+
+
+PREC_TOL = {"fp32": 2e-5, "bf16x3": 2e-4, "bf16": 3e-2}
 
 
 CONV_CASES = [
@@ -58,8 +66,10 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16"])
 @pytest.mark.parametrize("op,cin,cout,size,n", CONV_CASES)
-def test_conv_family_fwd_dgrad_wgrad(hip, op, cin, cout, size, n):
+def test_conv_family_fwd_dgrad_wgrad(hip, op, cin, cout, size, n, prec):
+    tol = PREC_TOL[prec]
     from cwf import functional as CF
     torch.manual_seed(0)
     d, h, w_ = size
@@ -70,7 +80,8 @@ def test_conv_family_fwd_dgrad_wgrad(hip, op, cin, cout, size, n):
     in_scale = rnd(n, cin, seed=4).abs() + 0.5
     in_shift = rnd(n, cin, seed=5)
     out_scale = (rnd(n, cout, seed=6) > -0.5).float() * 1.25
-    spec = _packed(CF.ConvSpec(op, cin, cout), w)
+    spec = _packed(CF.ConvSpec(op, cin, cout), w, prec)
+    wf, wd = (spec.wpk_f, spec.wpk_d) if prec == "fp32" else (spec.wpk16_f, spec.wpk16_d)
     do, ho, wo = pk.out_dims(op, d, h, w_)
     res = rnd(n, do, ho, wo, cout, seed=7) if cout % 4 == 0 else None
 
@@ -78,29 +89,29 @@ def test_conv_family_fwd_dgrad_wgrad(hip, op, cin, cout, size, n):
     st_ref = E.new_stats(n, cout, None)
     y_ref = E.conv(op, x, None, b, cout, in_scale, in_shift, 0.01, res, out_scale, st_ref, w_ref=w, out_channels_alloc=spec.cout_alloc)
     st = hip.new_stats(n, cout, DEV)
-    y = hip.conv(op, x.to(DEV), spec.wpk_f, b.to(DEV), cout, in_scale.to(DEV), in_shift.to(DEV), 0.01, None if res is None else res.to(DEV), out_scale.to(DEV), st,
-                 out_channels_alloc=spec.cout_alloc)
-    close(y, y_ref, what="fwd")
-    close(st, st_ref, rtol=1e-5, what="stats")
+    y = hip.conv(op, x.to(DEV), wf, b.to(DEV), cout, in_scale.to(DEV), in_shift.to(DEV), 0.01, None if res is None else res.to(DEV), out_scale.to(DEV), st,
+                 out_channels_alloc=spec.cout_alloc, prec=prec)
+    close(y, y_ref, rtol=tol, what="fwd")
+    close(st, st_ref, rtol=max(1e-5, tol), what="stats")
     # ---- plain forward (no prologue / epilogue extras)
     y2_ref = E.conv(op, x, None, None, cout, w_ref=w, out_channels_alloc=spec.cout_alloc)
-    y2 = hip.conv(op, x.to(DEV), spec.wpk_f, None, cout, out_channels_alloc=spec.cout_alloc)
-    close(y2, y2_ref, what="fwd plain")
+    y2 = hip.conv(op, x.to(DEV), wf, None, cout, out_channels_alloc=spec.cout_alloc, prec=prec)
+    close(y2, y2_ref, rtol=tol, what="fwd plain")
 
     # ---- data gradient
     dy = torch.zeros(n, do, ho, wo, spec.cout_alloc)
     dy[..., :cout] = rnd(n, do, ho, wo, cout, seed=8)
     dx_ref = E.conv(pk.dgrad_op(op), dy, None, None, cin, out=torch.empty(n, d, h, w_, cin), w_ref=w, fwd_op=op)
-    dx = hip.conv(pk.dgrad_op(op), dy.to(DEV), spec.wpk_d, None, cin, out=torch.empty((n, d, h, w_, cin), device=DEV))
-    close(dx, dx_ref, what="dgrad")
+    dx = hip.conv(pk.dgrad_op(op), dy.to(DEV), wd, None, cin, out=torch.empty((n, d, h, w_, cin), device=DEV), prec=prec)
+    close(dx, dx_ref, rtol=tol, what="dgrad")
 
     # ---- weight / bias gradient with the recomputed prologue
     dyv = dy[..., :cout]
     gw_ref, gb_ref = E.wgrad(op, x, in_scale, in_shift, 0.0, dyv, cout, None, spec.has_bias_map, w.numel(), w_ref_shape=w.shape)
-    gw, gb = hip.wgrad(op, x.to(DEV), in_scale.to(DEV), in_shift.to(DEV), 0.0, dy.to(DEV)[..., :cout], cout, spec.inv_map, spec.has_bias_map, w.numel())
-    close(gw, gw_ref, rtol=5e-5, what="wgrad")
+    gw, gb = hip.wgrad(op, x.to(DEV), in_scale.to(DEV), in_shift.to(DEV), 0.0, dy.to(DEV)[..., :cout], cout, spec.inv_map, spec.has_bias_map, w.numel(), prec=prec)
+    close(gw, gw_ref, rtol=max(5e-5, tol), what="wgrad")
     if gb is not None:
-        close(gb, gb_ref, rtol=5e-5, what="bgrad")
+        close(gb, gb_ref, rtol=max(5e-5, tol), what="bgrad")
 
 
 def test_gather_batched_matches_index_maps(hip):

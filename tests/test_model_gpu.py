@@ -35,8 +35,19 @@ def _losses(outs, target, edge):
             tools.get_edge_separate_loss(outs[4], edge)]
 
 
+@pytest.fixture()
+def precision_mode(request):
+    from cwf import kernels
+    kernels.set_precision(request.param)
+    yield request.param
+    kernels.set_precision("fp32")
+
+
+@pytest.mark.parametrize("precision_mode", ["fp32", "bf16x3"], indirect=True)
 @pytest.mark.parametrize("tag,size", [("64", (64, 64, 64)), ("128", (128, 128, 128))])
-def test_forward_backward_vs_reference_golden(hip, tag, size):
+def test_forward_backward_vs_reference_golden(hip, tag, size, precision_mode):
+    """fp32: exact-f32 MFMA.  bf16x3: split-bf16 MFMA operands (hi.hi + hi.lo + lo.hi, fp32 accumulate) -- the throughput
+    mode; it must meet the same 1e-3 logits/probability bound of BASELINE.json against the fp32 CPU reference."""
     g = np.load(os.path.join(GOLDEN, "model_%s.npz" % tag))
     m = _model().eval()
     m.collect_aux = True
@@ -47,7 +58,7 @@ def test_forward_backward_vs_reference_golden(hip, tag, size):
     for k in g.files:
         if k.startswith("topk_"):
             got, ref = set(m.aux[k[5:]][0].tolist()), set(g[k][0].tolist())
-            assert len(got ^ ref) <= 2, (k, len(got ^ ref))
+            assert len(got ^ ref) <= (2 if precision_mode == "fp32" else 4), (k, len(got ^ ref))
     # ---- probabilities and logits, 1e-3 relative (north_star); achieved is ~1e-5
     prob = outs[0].detach().reshape(-1)[torch.from_numpy(g["prob_sample_idx"]).to(DEV)].cpu().numpy()
     assert np.abs(prob - g["prob_sample"]).max() <= 1e-3 * np.abs(g["prob_sample"]).max()
@@ -77,7 +88,7 @@ def test_forward_backward_vs_reference_golden(hip, tag, size):
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
         if l2[i] > 1e-7:
             got = float(p.grad.double().norm())
-            if abs(got - l2[i]) > max(10 * noise[i], 1e-2) * l2[i]:
+            if abs(got - l2[i]) > max(10 * noise[i], 1e-2 if precision_mode == "fp32" else 3e-2) * l2[i]:
                 bad.append((n, got, float(l2[i])))
     assert not bad, bad[:10]
     for key in g.files:
@@ -86,7 +97,7 @@ def test_forward_backward_vs_reference_golden(hip, tag, size):
             ref = torch.from_numpy(g[key]).double()
             got = dict(m.named_parameters())[n].grad.double().cpu()
             if float(ref.norm()) > 1e-7:
-                assert float((got - ref).norm() / ref.norm()) < max(10 * noise[names.index(n)], 1e-2), n
+                assert float((got - ref).norm() / ref.norm()) < max(10 * noise[names.index(n)], 1e-2 if precision_mode == "fp32" else 3e-2), n
 
 
 def test_teacher_forced_topk_and_cpu_oracle_64(hip):
