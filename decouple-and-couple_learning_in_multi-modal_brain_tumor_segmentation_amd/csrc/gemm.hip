@@ -14,10 +14,13 @@ struct GemmArgs {
 };
 
 #define GT 64
-#define GK 16
-#define LDA_S 17
+#define GK 32
+#define LDA_S 33
 #define LDB_S 80
 
+// 64x64 output tile per workgroup, K in steps of 32.  The next K-tile is fetched into registers BEFORE the MFMAs of the
+// current one are issued (software pipelining): these GEMMs are tiny (M = 129..516 rows) and run at ~1 workgroup per CU, so
+// without the prefetch every K step pays a full L2 round trip.
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs a) {
   __shared__ float As[GT * LDA_S];
   __shared__ float Bs[GK * LDB_S];
@@ -37,20 +40,30 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs a) {
 
   const bool a_kfast = (a.sa_k == 1);
   const bool b_nfast = (a.sb_n == 1);
+  // element (m,k) / (k,n) handled by this thread in load slot i (8 slots each)
+  int am[8], ak[8], bk[8], bn[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (a_kfast) { ak[i] = tid & 31; am[i] = (tid >> 5) + 8 * i; } else { am[i] = tid & 63; ak[i] = (tid >> 6) + 4 * i; }
+    if (b_nfast) { bn[i] = tid & 63; bk[i] = (tid >> 6) + 4 * i; } else { bk[i] = tid & 31; bn[i] = (tid >> 5) + 8 * i; }
+  }
+  float ra[8], rb[8];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int gm = m0 + am[i], gk = k0 + ak[i];
+      ra[i] = (gm < a.M && gk < a.K) ? A[gm * a.sa_m + gk * a.sa_k] : 0.f;
+      const int gn = n0 + bn[i], gkb = k0 + bk[i];
+      rb[i] = (gn < a.N && gkb < a.K) ? B[gkb * a.sb_k + gn * a.sb_n] : 0.f;
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < a.K; k0 += GK) {
     if (k0) __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int m, k;
-      if (a_kfast) { k = tid & 15; m = (tid >> 4) + 16 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }
-      const int gm = m0 + m, gk = k0 + k;
-      As[m * LDA_S + k] = (gm < a.M && gk < a.K) ? A[gm * a.sa_m + gk * a.sa_k] : 0.f;
-      int n, kb;
-      if (b_nfast) { n = tid & 63; kb = (tid >> 6) + 4 * i; } else { kb = tid & 15; n = (tid >> 4) + 16 * i; }
-      const int gn = n0 + n, gkb = k0 + kb;
-      Bs[kb * LDB_S + n] = (gn < a.N && gkb < a.K) ? B[gkb * a.sb_k + gn * a.sb_n] : 0.f;
-    }
+    for (int i = 0; i < 8; ++i) { As[am[i] * LDA_S + ak[i]] = ra[i]; Bs[bk[i] * LDB_S + bn[i]] = rb[i]; }
     __syncthreads();
+    if (k0 + GK < a.K) fetch(k0 + GK);          // in flight while the MFMAs below run
 #pragma unroll
     for (int kk = 0; kk < GK / 4; ++kk) {
       float av[2], bv[2];

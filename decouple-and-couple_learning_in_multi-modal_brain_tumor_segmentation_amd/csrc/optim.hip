@@ -20,9 +20,10 @@ extern "C" int cwf_gather_batched(const struct cwf_gather_desc* table, int nlaye
   return 0;
 }
 
-__global__ void adam_kernel(const cwf_adam_desc* __restrict__ table, float step_size, float omb1, float beta2, float omb2, float eps, float wd,
-                            float bc2_sqrt, int amsgrad) {
+__global__ void adam_kernel(const cwf_adam_desc* __restrict__ table, const float* __restrict__ hyper, float step_size, float omb1, float beta2,
+                            float omb2, float eps, float wd, float bc2_sqrt, int amsgrad) {
   const cwf_adam_desc d = table[blockIdx.y];
+  if (hyper) { step_size = hyper[0]; bc2_sqrt = hyper[1]; }        // device-resident: survives hipGraph replay
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * blockDim.x) {
     const float p = d.p[i];
     const float g = d.g[i] + wd * p;                                 // grad.add(param, alpha=weight_decay)
@@ -37,13 +38,14 @@ __global__ void adam_kernel(const cwf_adam_desc* __restrict__ table, float step_
 }
 
 extern "C" int cwf_adam_amsgrad(const struct cwf_adam_desc* table, int ntensors, int64_t max_n,
-                                double lr, double beta1, double beta2, double eps, double weight_decay, int step, int amsgrad, void* stream) {
-  if (!table || ntensors <= 0 || max_n <= 0 || step <= 0) return CWF_E_BADARG;
-  const double bc1 = 1.0 - pow(beta1, (double)step);
-  const double bc2 = 1.0 - pow(beta2, (double)step);
+                                double lr, double beta1, double beta2, double eps, double weight_decay, int step, int amsgrad,
+                                const float* hyper_dev, void* stream) {
+  if (!table || ntensors <= 0 || max_n <= 0 || (step <= 0 && !hyper_dev)) return CWF_E_BADARG;
+  const double bc1 = 1.0 - pow(beta1, (double)(step > 0 ? step : 1));
+  const double bc2 = 1.0 - pow(beta2, (double)(step > 0 ? step : 1));
   int64_t gx = cdiv64(max_n, 256); if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gx, ntensors), dim3(256), 0, cwf_stream(stream), table, (float)(lr / bc1), (float)(1.0 - beta1),
-                     (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)sqrt(bc2), amsgrad);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gx, ntensors), dim3(256), 0, cwf_stream(stream), table, hyper_dev, (float)(lr / bc1),
+                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)sqrt(bc2), amsgrad);
   CWF_LAUNCH_CHECK();
   return 0;
 }

@@ -356,8 +356,9 @@ class HipBackend:
         return dprob
 
     # ------------------------------------------------------------------ K11 / misc
-    def adam(self, table, ntensors, max_n, lr, beta1, beta2, eps, wd, step, amsgrad):
-        self._call("cwf_adam_amsgrad", table.data_ptr(), ntensors, max_n, lr, beta1, beta2, eps, wd, step, int(amsgrad), self._stream())
+    def adam(self, table, ntensors, max_n, lr, beta1, beta2, eps, wd, step, amsgrad, hyper_dev=None):
+        self._call("cwf_adam_amsgrad", table.data_ptr(), ntensors, max_n, lr, beta1, beta2, eps, wd, step, int(amsgrad),
+                   _p(hyper_dev), self._stream())
 
     def mul(self, a, b):
         a, b = a.contiguous(), b.contiguous()

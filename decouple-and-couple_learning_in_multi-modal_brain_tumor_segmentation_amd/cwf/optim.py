@@ -4,7 +4,12 @@ Semantics and state layout are those of ``torch.optim.Adam(params, lr, weight_de
 uses it (train_no_amp.py:136,239): L2 decay folded into the gradient, bias-corrected first/second moments, running
 max of the second moment; ``state_dict()`` has the same keys ('step', 'exp_avg', 'exp_avg_sq', 'max_exp_avg_sq') so
 the checkpoint's 'optim_dict' (train_no_amp.py:252) stays interchangeable.  ``poly_lr`` is
-train_no_amp.adjust_learning_rate (:270-273)."""
+train_no_amp.adjust_learning_rate (:270-273).
+
+Gradients are gathered into ONE persistent flat fp32 buffer (``flat_grad``, 67 MB): the kernel's descriptor table is
+then static (safe for hipGraph capture / replay) and data-parallel training all-reduces that single buffer."""
+import math
+
 import numpy as np
 import torch
 
@@ -18,22 +23,71 @@ def poly_lr(init_lr, epoch, max_epoch, power=0.9):
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
-        self._tables = {}
+        if len(self.param_groups) != 1:
+            raise ValueError("FusedAdam supports one parameter group (the reference uses one, train_no_amp.py:136)")
+        self._plist = [p for p in self.param_groups[0]["params"] if p.requires_grad]
+        self.flat_grad = None
+        self._table = None
+        self._max_n = 0
+        self._hyper_dev = None
+        self._hyper_host = None
+        self._steps = 0
 
-    def _table(self, gi, plist):
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist)
-        hit = self._tables.get(gi)
-        if hit is not None and hit[0] == key:
-            return hit[1], hit[2]
-        rows = []
-        for p in plist:
+    # ------------------------------------------------------------------ setup
+    def _ensure(self):
+        if self._table is not None and self._table_key == tuple(p.data_ptr() for p in self._plist):
+            return
+        group = self.param_groups[0]
+        dev = self._plist[0].device
+        total = sum(p.numel() for p in self._plist)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        rows, off = [], 0
+        for p in self._plist:
             st = self.state[p]
-            rows.append([p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                         st["max_exp_avg_sq"].data_ptr() if "max_exp_avg_sq" in st else 0, p.numel()])
-        table = torch.tensor(rows, dtype=torch.int64).to(plist[0].device)
-        max_n = max(r[5] for r in rows)
-        self._tables[gi] = (key, table, max_n)
-        return table, max_n
+            if not st:
+                st["step"] = torch.tensor(float(self._steps))
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if group["amsgrad"]:
+                    st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            n = p.numel()
+            rows.append([p.data_ptr(), self.flat_grad.data_ptr() + 4 * off, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                         st["max_exp_avg_sq"].data_ptr() if "max_exp_avg_sq" in st else 0, n])
+            off += n
+        self._table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self._table_key = tuple(p.data_ptr() for p in self._plist)
+        self._max_n = max(r[5] for r in rows)
+        self._hyper_dev = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._hyper_host = torch.zeros(2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(2)
+
+    # ------------------------------------------------------------------ the three phases of a step
+    def gather_grads(self):
+        """p.grad -> flat_grad (one concatenation; capturable).  Parameters without a gradient contribute zeros."""
+        self._ensure()
+        torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self._plist], out=self.flat_grad)
+        return self.flat_grad
+
+    def advance_host(self):
+        """Host side of a step: step counter, bias corrections (double, as torch) -> device hyper buffer.  Call BEFORE
+        launching / replaying the kernel of the step."""
+        self._ensure()
+        group = self.param_groups[0]
+        self._steps += 1
+        for p in self._plist:
+            self.state[p]["step"] += 1
+        b1, b2 = group["betas"]
+        bc1 = 1.0 - b1 ** self._steps
+        bc2 = 1.0 - b2 ** self._steps
+        self._hyper_host[0] = group["lr"] / bc1
+        self._hyper_host[1] = math.sqrt(bc2)
+        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+
+    def launch(self):
+        """The single fused kernel (capturable: every argument is static, the schedule lives in the device hyper buffer)."""
+        group = self.param_groups[0]
+        b1, b2 = group["betas"]
+        backend().adam(self._table, len(self._plist), self._max_n, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
+                       0, group["amsgrad"], hyper_dev=self._hyper_dev)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -41,24 +95,7 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        K = backend()
-        for gi, group in enumerate(self.param_groups):
-            plist = [p for p in group["params"] if p.grad is not None]
-            if not plist:
-                continue
-            for p in plist:
-                st = self.state[p]
-                if not st:
-                    st["step"] = torch.tensor(0.0)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    if group["amsgrad"]:
-                        st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                if not p.grad.is_contiguous():
-                    p.grad = p.grad.contiguous()
-                st["step"] += 1
-            step = int(self.state[plist[0]]["step"])
-            table, max_n = self._table(gi, plist)
-            b1, b2 = group["betas"]
-            K.adam(table, len(plist), max_n, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], step, group["amsgrad"])
+        self.gather_grads()
+        self.advance_host()
+        self.launch()
         return loss

@@ -221,7 +221,10 @@ int cwf_dice_ce_bwd(const float* prob, const int64_t* label, uint32_t posmask, c
 struct cwf_adam_desc { float* p; const float* g; float* m; float* v; float* vmax; int64_t n; };
 int cwf_adam_amsgrad(const struct cwf_adam_desc* table, int ntensors, int64_t max_n,
                      double lr, double beta1, double beta2, double eps, double weight_decay, int step, int amsgrad,
-                     void* stream);   /* hyper-parameters in double: torch derives step_size / bias corrections in double */
+                     const float* hyper_dev, void* stream);
+/* hyper-parameters in double: torch derives step_size = lr/(1-beta1^t) and sqrt(1-beta2^t) in double.  hyper_dev
+ * (nullable): device float[2] = {step_size, sqrt(1-beta2^t)} overriding the values derived from lr/step -- lets the
+ * launch be captured in a hipGraph and replayed while the host advances the schedule.                                  */
 
 /* ------------------------------------------------------------------------------------------------
  * K12 / misc elementwise
