@@ -18,6 +18,7 @@ struct ConvArgsB {
   const float* x; const uint4* wpk; const float* bias; float* y;
   const float* in_scale; const float* in_shift; float in_slope;
   const float* residual; int r_ldc; const float* out_scale; double* stats;
+  unsigned long long* diag;
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -204,6 +205,286 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// conv16: the 3x3x3 stride-1 convolutions with <= 16 input and <= 16 output channels (every conv at full
+// resolution: 44 % of the model's FLOPs, the step's dominant kernel).  Same math and packed-weight layout as
+// conv_bf16_kernel<4,1,4>, restructured after profiling it (rocprofv3 PMC, profiles/): HBM traffic was 1.1x the
+// algorithmic bytes and LDS conflict-free, but the MFMA pipe was 14 % busy -- waves spent their time issuing ~8 VALU
+// instructions per MFMA (staging index arithmetic, bf16 splitting, epilogue addressing) and waiting on their own loads.
+//   * producer / consumer waves: a workgroup is 8 waves, one per CU.  Waves 0-3 ("MFMA waves", one per SIMD) hold the whole
+//     weight set in registers (14 tap pairs x (hi|lo) x 16 B per lane) and do nothing but LDS reads, MFMAs and the epilogue;
+//     waves 4-7 ("loader waves", their SIMD partners) fetch the next halo tile from HBM, apply InstanceNorm + activation,
+//     split to bf16 hi/lo and write the OTHER LDS buffer.  The matrix pipe and the VALU/memory pipes of a SIMD run side by
+//     side; one barrier per tile hands the buffers over.
+//   * persistent workgroups walk the 4x4x16 output tiles; a tile's global loads are issued a full tile ahead.
+//   * tile geometry is compile-time (6x6x18 halo): LDS offsets are immediates; the loader keeps one precomputed
+//     voxel-relative offset per staging slot and adds it to a scalar tile base (no div/mod or 64-bit math per voxel).
+// ---------------------------------------------------------------------------------------------------
+#define C16_TD 4
+#define C16_TH 4
+#define C16_ID 6
+#define C16_IH 6
+#define C16_IW 18
+#define C16_NVOX (C16_ID * C16_IH * C16_IW)          // 648
+#define C16_SLOTS ((C16_NVOX + 63) / 64)             // 11 staging slots per loader thread (4 threads per voxel)
+
+// In-kernel phase stamps (diagnostic build only, DIAG = true: cwf_debug_conv16_diag): s_memtime per phase and wave role.
+#define CWF_STAMP(v) unsigned long long v = 0; if (DIAG) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+
+template <bool X3, bool DIAG>
+__global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int total_tiles) {
+  extern __shared__ float4 lds4[];
+  const ConvGeom& g = a.g;
+  constexpr int IMG = C16_NVOX * 16;                   // bf16 elements per image
+  constexpr int BUF = IMG * (X3 ? 2 : 1);              // per buffer: hi image (+ lo image)
+  unsigned short* lds = reinterpret_cast<unsigned short*>(lds4);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_sp = g.tiles_d * g.tiles_h * g.tiles_w;
+  const int first = blockIdx.x;
+  if (first >= total_tiles) return;                    // uniform for the whole workgroup
+  const int niter = (total_tiles - first + (int)gridDim.x - 1) / (int)gridDim.x;
+
+  if (wave < 4) {
+    // =============================================================== MFMA waves
+    const int r = lane & 15, kq = lane >> 4;
+    const bool second = (kq >> 1) != 0;
+    // hi weight images in registers (56 VGPRs); lo images in LDS, lane-linear [14][64] x 16 B (conflict-free), fetched with the
+    // A fragments one tap pair ahead.  (hi + lo both in registers spills next to the double-buffered A fragments.)
+    uint4 bh[14];
+    const uint4* wl = reinterpret_cast<const uint4*>(lds + 2 * BUF) + lane;
+    {
+      const uint4* wp = a.wpk + lane * 2;
+#pragma unroll
+      for (int s = 0; s < 14; ++s) bh[s] = wp[s * 128];
+      if (X3) {
+        uint4* wls = reinterpret_cast<uint4*>(lds + 2 * BUF);
+        for (int i = tid; i < 14 * 64; i += 256) wls[i] = a.wpk[(i >> 6) * 128 + (i & 63) * 2 + 1];
+      }
+    }
+    int abase[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) abase[m] = (((wave * C16_IH + m) * C16_IW + r) * 16 + (kq & 1) * 8) * 2;
+    const float bv = (a.bias && r < g.Cout) ? a.bias[r] : 0.f;
+    const int ylane = kq * 4 * g.y_ldc + r;
+    const int rlane = kq * 4 * a.r_ldc + r;
+    // InstanceNorm statistics of the output: kept in registers over this workgroup's tiles, flushed with one f64 atomic
+    // pair per wave and channel when the sample index changes and at the end.
+    float s1 = 0.f, s2 = 0.f;
+    int stat_n = first / tiles_sp;
+    auto flush_stats = [&](int n_) {
+      float u1 = s1, u2 = s2;
+      u1 += __shfl_xor(u1, 16, 64); u1 += __shfl_xor(u1, 32, 64);
+      u2 += __shfl_xor(u2, 16, 64); u2 += __shfl_xor(u2, 32, 64);
+      if (kq == 0 && r < g.Cout) {
+        atomic_add_f64(a.stats + ((int64_t)n_ * g.Cout + r) * 2 + 0, (double)u1);
+        atomic_add_f64(a.stats + ((int64_t)n_ * g.Cout + r) * 2 + 1, (double)u2);
+      }
+      s1 = 0.f; s2 = 0.f;
+    };
+
+    unsigned long long d_bar = 0, d_mfma = 0, d_epi = 0;
+    for (int it = 0; it < niter; ++it) {
+      const int tile = first + it * (int)gridDim.x;
+      CWF_STAMP(t0);
+      // Raw barrier: __syncthreads() would add s_waitcnt vmcnt(0) and make this wave wait for its own output stores.
+      asm volatile("s_barrier" ::: "memory");            // buffer it&1 is complete
+      CWF_STAMP(t1);
+      const char* xhb = reinterpret_cast<const char*>(lds + (it & 1) * BUF);
+      const char* xlb = xhb + IMG * 2;
+      f32x4 acc[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // A fragments are double-buffered in registers: the 8 LDS reads of tap pair s+1 are issued BEFORE the 12 MFMAs of
+      // pair s (one MFMA wave per SIMD: nothing else hides the LDS latency).  sched_barrier pins that order.
+      uint4 fa[2][4], fl[2][4], fb[2];
+      auto load_step = [&](int s_, int b_) {
+        if (X3) fb[b_] = wl[s_ * 64];
+        const int ta = 2 * s_, tb = (2 * s_ + 1 < 27) ? 2 * s_ + 1 : 2 * s_;
+        const int oa = (((ta / 9) * C16_IH + (ta / 3) % 3) * C16_IW + ta % 3) * 32;
+        const int ob = (((tb / 9) * C16_IH + (tb / 3) % 3) * C16_IW + tb % 3) * 32;
+        const int to = second ? ob : oa;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          fa[b_][m] = *reinterpret_cast<const uint4*>(xhb + abase[m] + to);
+          if (X3) fl[b_][m] = *reinterpret_cast<const uint4*>(xlb + abase[m] + to);
+        }
+      };
+      load_step(0, 0);
+#pragma unroll
+      for (int s = 0; s < 14; ++s) {
+        if (s + 1 < 14) load_step(s + 1, (s + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][m]), __builtin_bit_cast(bf16x8, bh[s]), acc[m], 0, 0, 0);
+          if (X3) {
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][m]), __builtin_bit_cast(bf16x8, fb[s & 1]), acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fl[s & 1][m]), __builtin_bit_cast(bf16x8, bh[s]), acc[m], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      CWF_STAMP(t2);
+      // ---- epilogue (uniform tile base + lane offset).  A variant that transposes the accumulators through LDS and stores
+      // one contiguous 1 KiB dwordx4 per M-tile was measured SLOWER (0.54 vs 0.42 ms): the kernel is bound by the L1's
+      // outstanding-miss capacity (TCP_PENDING_STALL ~58 % of CU cycles), and wider bursts make that worse.
+      const int n = tile / tiles_sp; int rem = tile - n * tiles_sp;
+      const int tile_w = rem % g.tiles_w; rem /= g.tiles_w;
+      const int tile_h = rem % g.tiles_h; const int tile_d = rem / g.tiles_h;
+      const int od = tile_d * C16_TD + wave, oh0 = tile_h * C16_TH, ow0 = tile_w * 16;
+      if (a.stats && n != stat_n) { flush_stats(stat_n); stat_n = n; }     // wave-uniform
+      if (od < g.Do) {                                                      // wave-uniform
+        const int64_t vox0 = (((int64_t)n * g.Do + od) * g.Ho + oh0) * g.Wo + ow0;
+        float* yb = a.y + vox0 * g.y_ldc;
+        const float* rb = a.residual ? a.residual + vox0 * a.r_ldc : nullptr;
+        const float osc = (a.out_scale && r < g.Cout) ? a.out_scale[(int64_t)n * g.Cout + r] : 1.f;
+        const bool full = (oh0 + C16_TH <= g.Ho) && (ow0 + 16 <= g.Wo) && r < g.Cout;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bool ok = full || (r < g.Cout && oh0 + m < g.Ho && ow0 + kq * 4 + i < g.Wo);
+            if (!ok) continue;
+            const int eo = m * g.Wo + i;                                    // uniform part, in voxels
+            float v = acc[m][i] + bv;
+            if (rb) v += rb[eo * a.r_ldc + rlane];
+            v *= osc;
+            yb[eo * g.y_ldc + ylane] = v;
+            s1 += v; s2 += v * v;
+          }
+        }
+      }
+      CWF_STAMP(t3);
+      if (DIAG) { d_bar += t1 - t0; d_mfma += t2 - t1; d_epi += t3 - t2; }
+    }
+    if (a.stats) flush_stats(stat_n);
+    if (DIAG && a.diag && lane == 0) {
+      unsigned long long* o = a.diag + ((int64_t)blockIdx.x * 8 + wave) * 4;
+      o[0] = d_bar; o[1] = d_mfma; o[2] = d_epi; o[3] = 0;
+    }
+  } else {
+    // =============================================================== loader waves
+    const int lt = tid - 256;                            // 0..255
+    const int q = lt & 3;
+    const int c = q * 4;
+    const bool cval = c < g.Cin;
+    const bool has_norm = a.in_scale != nullptr;
+    const float slope = a.in_slope;
+    const int HW = g.Hi * g.Wi;
+    int rel[C16_SLOTS];
+#pragma unroll
+    for (int i = 0; i < C16_SLOTS; ++i) {
+      const int v = (lt >> 2) + 64 * i;
+      const int iw = v % C16_IW, t2 = v / C16_IW;
+      const int ih = t2 % C16_IH, idd = t2 / C16_IH;
+      rel[i] = (idd * HW + ih * g.Wi + iw) * g.x_ldc + c;
+    }
+    const bool last_slot_ok = (lt >> 2) + 64 * (C16_SLOTS - 1) < C16_NVOX;
+    float4 pre[C16_SLOTS];
+    unsigned pre_inb = 0;
+    auto fetch = [&](int tile) {
+      const int n = tile / tiles_sp; int rem = tile - n * tiles_sp;
+      const int tile_w = rem % g.tiles_w; rem /= g.tiles_w;
+      const int tile_h = rem % g.tiles_h; const int tile_d = rem / g.tiles_h;
+      const int id0 = tile_d * C16_TD - 1, ih0 = tile_h * C16_TH - 1, iw0 = tile_w * 16 - 1;
+      const float* base = a.x + ((((int64_t)n * g.Di + id0) * g.Hi + ih0) * g.Wi + iw0) * g.x_ldc;   // uniform
+      const bool interior = id0 >= 0 && id0 + C16_ID <= g.Di && ih0 >= 0 && ih0 + C16_IH <= g.Hi && iw0 >= 0 && iw0 + C16_IW <= g.Wi;
+      pre_inb = 0;
+#pragma unroll
+      for (int i = 0; i < C16_SLOTS; ++i) {
+        pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool ok = cval && (i < C16_SLOTS - 1 || last_slot_ok);
+        if (!interior) {                                 // wave-uniform branch: border tiles only
+          const int v = (lt >> 2) + 64 * i;
+          const int iw = v % C16_IW, t2 = v / C16_IW;
+          const int ih = t2 % C16_IH, idd = t2 / C16_IH;
+          const int gd = id0 + idd, gh = ih0 + ih, gw = iw0 + iw;
+          ok = ok && gd >= 0 && gd < g.Di && gh >= 0 && gh < g.Hi && gw >= 0 && gw < g.Wi;
+        }
+        if (ok) { pre[i] = *reinterpret_cast<const float4*>(base + rel[i]); pre_inb |= 1u << i; }
+      }
+    };
+    auto commit = [&](int tile, int buf) {               // registers -> (norm, act, bf16 split) -> LDS buffer
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_norm && cval) {
+        const int n = tile / tiles_sp;
+        sc = *reinterpret_cast<const float4*>(a.in_scale + (int64_t)n * g.Cin + c);
+        sh = *reinterpret_cast<const float4*>(a.in_shift + (int64_t)n * g.Cin + c);
+      }
+      unsigned short* dh = lds + buf * BUF + (lt >> 2) * 16 + q * 4;
+      unsigned short* dl = dh + IMG;
+#pragma unroll
+      for (int i = 0; i < C16_SLOTS; ++i) {
+        if (i == C16_SLOTS - 1 && !last_slot_ok) continue;
+        float4 val = pre[i];
+        if ((has_norm || slope != 1.f) && ((pre_inb >> i) & 1u)) {
+          val.x = cwf_act(val.x * sc.x + sh.x, slope); val.y = cwf_act(val.y * sc.y + sh.y, slope);
+          val.z = cwf_act(val.z * sc.z + sh.z, slope); val.w = cwf_act(val.w * sc.w + sh.w, slope);
+        }
+        uint2 h; h.x = pack_bf16(val.x, val.y); h.y = pack_bf16(val.z, val.w);
+        *reinterpret_cast<uint2*>(dh + i * 64 * 16) = h;
+        if (X3) {
+          uint2 l;
+          l.x = pack_bf16(val.x - bf16_round(val.x), val.y - bf16_round(val.y));
+          l.y = pack_bf16(val.z - bf16_round(val.z), val.w - bf16_round(val.w));
+          *reinterpret_cast<uint2*>(dl + i * 64 * 16) = l;
+        }
+      }
+    };
+    const int G = (int)gridDim.x;
+    unsigned long long d_bar = 0, d_wait = 0, d_commit = 0, d_fetch = 0;
+    fetch(first);
+    commit(first, 0);
+    if (niter > 1) fetch(first + G);
+    for (int it = 0; it < niter; ++it) {
+      CWF_STAMP(t0);
+      // LDS writes done -> barrier.  Raw form: __syncthreads() would also wait (vmcnt(0)) for the prefetch in flight.
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // buffer it&1 handed over; buffer (it+1)&1 is free
+      CWF_STAMP(t1);
+      if (it + 1 < niter) {
+        if (DIAG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CWF_STAMP(t2);
+        commit(first + (it + 1) * G, (it + 1) & 1);
+        if (DIAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        CWF_STAMP(t3);
+        if (it + 2 < niter) fetch(first + (it + 2) * G);
+        CWF_STAMP(t4);
+        if (DIAG) { d_wait += t2 - t1; d_commit += t3 - t2; d_fetch += t4 - t3; }
+      }
+      if (DIAG) d_bar += t1 - t0;
+    }
+    if (DIAG && a.diag && lane == 0) {
+      unsigned long long* o = a.diag + ((int64_t)blockIdx.x * 8 + wave) * 4;
+      o[0] = d_bar; o[1] = d_wait; o[2] = d_commit; o[3] = d_fetch;
+    }
+  }
+}
+
+static unsigned long long* g_conv16_diag = nullptr;
+extern "C" void cwf_debug_conv16_diag(unsigned long long* buf) { g_conv16_diag = buf; }   // [256][8][4] u64, or NULL = off
+
+template <bool X3, bool DIAG>
+static int launch_conv16_impl(ConvArgsB a, hipStream_t st) {
+  const ConvGeom& g = a.g;
+  const int total = g.N * g.tiles_d * g.tiles_h * g.tiles_w;
+  const size_t lds = (size_t)2 * C16_NVOX * 16 * sizeof(unsigned short) * (X3 ? 2 : 1) + (X3 ? 14 * 64 * 16 : 0);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv16_kernel<X3, DIAG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  a.diag = DIAG ? g_conv16_diag : nullptr;
+  int grid = 256; if (grid > total) grid = total;          // one 8-wave workgroup per CU
+  hipLaunchKernelGGL((conv16_kernel<X3, DIAG>), dim3(grid), dim3(512), lds, st, a, total);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+template <bool X3>
+static int launch_conv16(const ConvArgsB& a, hipStream_t st) {
+  return g_conv16_diag ? launch_conv16_impl<X3, true>(a, st) : launch_conv16_impl<X3, false>(a, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // weight packing: dst[(i/8)*16 + i%8] = hi(src[map[i]]), dst[(i/8)*16 + 8 + i%8] = lo(...)   (bf16, zeros where map < 0)
 // ---------------------------------------------------------------------------------------------------
 __global__ void gather_split_bf16_kernel(const cwf_gather_desc* __restrict__ table) {
@@ -292,6 +573,12 @@ extern "C" int cwf_conv_mfma_bf16(int op, int x3, const float* x, int x_ldc, con
   a.x = x; a.wpk = reinterpret_cast<const uint4*>(wpk16); a.bias = bias; a.y = y; a.in_scale = in_scale; a.in_shift = in_shift;
   a.in_slope = in_slope; a.residual = residual; a.r_ldc = r_ldc; a.out_scale = out_scale; a.stats = stats;
   hipStream_t st = cwf_stream(stream);
+  if (op == CWF_CONV3_S1 && Cin <= 16 && Cout <= 16 && (int64_t)Do * Ho * Wo >= 32768) {
+    // full-resolution 16-channel convs: the persistent register-resident-weight kernel (tile 4x4x16)
+    rc = cwf_build_geom(a.g, op, N, Di, Hi, Wi, Cin, x_ldc, Do, Ho, Wo, Cout, y_ldc, 16);
+    if (rc) return rc;
+    return x3 ? launch_conv16<true>(a, st) : launch_conv16<false>(a, st);
+  }
 #define CWF_CFG(mt, nt, wm) if (c.MT == mt && c.NT == nt && c.WM == wm) return x3 ? launch_cfg<mt, nt, wm, true>(a, st) : launch_cfg<mt, nt, wm, false>(a, st);
   CWF_CFG(4, 4, 1) CWF_CFG(2, 4, 2) CWF_CFG(2, 4, 4) CWF_CFG(4, 2, 4) CWF_CFG(4, 1, 4)
   CWF_CFG(1, 4, 4) CWF_CFG(1, 2, 4) CWF_CFG(1, 2, 2) CWF_CFG(1, 1, 4)

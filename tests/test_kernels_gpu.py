@@ -49,6 +49,8 @@ CONV_CASES = [
     # op, cin, cout, size (D,H,W), batch
     (pk.CONV3_S1, 4, 16, (8, 12, 20), 2),
     (pk.CONV3_S1, 16, 16, (16, 16, 32), 1),
+    (pk.CONV3_S1, 16, 16, (36, 30, 40), 2),      # >= 32768 voxels: the persistent conv16 kernel, ragged tiles
+    (pk.CONV3_S1, 4, 16, (32, 32, 32), 2),
     (pk.CONV3_S1, 32, 32, (8, 8, 16), 1),
     (pk.CONV3_S1, 96, 32, (8, 8, 8), 1),
     (pk.CONV3_S1, 256, 128, (4, 6, 6), 1),

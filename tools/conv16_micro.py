@@ -1,0 +1,47 @@
+"""Micro-benchmark of the dominant kernel (3x3x3 conv 16->16 @128^3 x2) for rocprofv3 PMC runs."""
+import os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "decouple-and-couple_learning_in_multi-modal_brain_tumor_segmentation_amd")); sys.path.insert(0, REPO)
+import torch
+from cwf import functional as CF, packing as pk, kernels
+prec = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+what = sys.argv[3] if len(sys.argv) > 3 else "conv"
+kernels.set_precision(prec)
+K = kernels.backend()
+dev = "cuda:0"
+n, s, c = 2, 128, 16
+x = torch.randn((n, s, s, s, c), device=dev)
+w = torch.nn.Parameter(torch.randn((c, c, 3, 3, 3), device=dev) * 0.05)
+b = torch.zeros(c, device=dev)
+spec = CF.ConvSpec(pk.CONV3_S1, c, c)
+packer = CF.WeightPacker(); packer.add(spec, w); packer.refresh()
+sc = torch.ones((n, c), device=dev); sh = torch.zeros((n, c), device=dev)
+y = torch.empty_like(x); dy = torch.randn_like(x)
+stats = K.new_stats(n, c, dev)
+def run():
+    if what == "conv":
+        K.conv(pk.CONV3_S1, x, spec.packed(False), b, c, sc, sh, 0.0, None, None, stats, out=y)
+    else:
+        K.wgrad(pk.CONV3_S1, x, sc, sh, 0.0, dy, c, spec.inv_map, True, w.numel())
+for _ in range(3): run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(iters): run()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / iters
+print("%s %s: %.4f ms  %.1f TFLOP/s alg  %.1f GB/s alg" % (what, prec, ms, 2.0 * 27 * c * c * n * s ** 3 / ms / 1e9, 2.0 * n * s ** 3 * c * 4 / ms / 1e6))
+if os.environ.get("CWF_DIAG"):
+    import ctypes
+    diag = torch.zeros((256, 8, 4), dtype=torch.int64, device=dev)
+    K.lib.cwf_debug_conv16_diag.argtypes = [ctypes.c_void_p]; K.lib.cwf_debug_conv16_diag.restype = None
+    K.lib.cwf_debug_conv16_diag(diag.data_ptr())
+    run(); torch.cuda.synchronize()
+    K.lib.cwf_debug_conv16_diag(None)
+    d = diag.cpu().double()
+    tiles = 2 * 8192 / 256
+    m = d[:, :4].mean((0, 1)) / tiles
+    l = d[:, 4:].mean((0, 1)) / tiles
+    print("per tile cycles (s_memtime ticks)  MFMA waves: barrier %.0f  mfma %.0f  epilogue %.0f" % (m[0], m[1], m[2]))
+    print("per tile cycles                  loader waves: barrier %.0f  loadwait %.0f  commit %.0f  fetch %.0f" % (l[0], l[1], l[2], l[3]))
