@@ -49,9 +49,18 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-def dominant_kernel_roofline(dev, iters=20):
-    """cwf_conv_mfma on the shape that dominates the step: 3x3x3, 16->16 channels, 128^3, batch 2, with the fused
-    InstanceNorm+ReLU prologue and statistics epilogue it runs with inside EnBlock / DeBlock."""
+# HBM bytes per launch of the dominant kernel measured with rocprofv3 --pmc (FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE),
+# profiles/round1_conv16_pmc_summary.txt: 2 x 160.1 MB + 264.2 MB.  Re-measure when the kernel changes.
+MEASURED_HBM_BYTES_CONV16 = {"bf16x3": 584.4e6, "bf16": None, "fp32": None}
+MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0 / 3.0, "bf16": 2500.0}   # dense peaks; bf16x3 issues 3 MFMAs per product
+
+
+def dominant_kernel_roofline(dev, precision, iters=20):
+    """The step's dominant kernel: 3x3x3 conv, 16->16 channels, 128^3, batch 2 (all eight full-resolution convs of the
+    encoder/decoder blocks and their data gradients run it), with the fused InstanceNorm+ReLU prologue and the statistics
+    epilogue it has inside EnBlock / DeBlock.  fp32 mode: conv_mfma_kernel<4,1,4> (exact f32 MFMA, MFMA-bound: AI 108 F/B
+    > ridge 19.6).  bf16x3 / bf16 modes: conv16_kernel (split-bf16 MFMA operands, fp32 storage): HBM-bound by design --
+    algorithmic bytes = x read once + y written once in fp32 = 2*N*V*16*4 B per launch."""
     from cwf import functional as CF, packing as pk
     from cwf.kernels import backend
     K = backend()
@@ -68,22 +77,29 @@ def dominant_kernel_roofline(dev, iters=20):
     y = torch.empty_like(x)
     stats = K.new_stats(n, c, dev)
     for _ in range(3):
-        K.conv(pk.CONV3_S1, x, spec.wpk_f, b, c, sc, sh, 0.0, None, None, stats, out=y)
+        K.conv(pk.CONV3_S1, x, spec.packed(False), b, c, sc, sh, 0.0, None, None, stats, out=y)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(iters):
-        K.conv(pk.CONV3_S1, x, spec.wpk_f, b, c, sc, sh, 0.0, None, None, stats, out=y)
+        K.conv(pk.CONV3_S1, x, spec.packed(False), b, c, sc, sh, 0.0, None, None, stats, out=y)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * 27 * c * c * n * s ** 3
     alg_bytes = 2.0 * n * s ** 3 * c * 4          # read x once + write y once, fp32
-    achieved = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "conv_mfma_kernel<4,1,4> 3x3x3 16->16 @128^3 x2", "bound": "mfma", "achieved": round(achieved, 2),
-            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": None, "avg_launch_ms": round(ms, 4), "algorithmic_gbytes_per_s": round(alg_bytes / (ms * 1e-3) / 1e9, 1),
-            "hbm_frac_of_8TBs": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    tflops = flops / (ms * 1e-3) / 1e12
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    if precision == "fp32":
+        out = {"kernel": "conv_mfma_kernel<4,1,4> (v_mfma_f32_16x16x4_f32) 3x3x3 16->16 @128^3 x2", "bound": "mfma",
+               "achieved": round(tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4)}
+    else:
+        out = {"kernel": "conv16_kernel<%s> (v_mfma_f32_16x16x32_bf16, fp32 storage) 3x3x3 16->16 @128^3 x2" % precision, "bound": "hbm",
+               "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    out.update({"traffic": MEASURED_HBM_BYTES_CONV16.get(precision), "avg_launch_ms": round(ms, 4),
+                "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": flops,
+                "algorithmic_tflops": round(tflops, 2), "frac_of_mfma_peak_for_mode": round(tflops / MFMA_PEAK_TFLOPS[precision], 4)})
+    return out
 
 
 def cpu_baseline(steps=2):
@@ -178,16 +194,18 @@ def main():
         out = {
             "metric": "training volumes/sec (4x128^3)", "value": round(value, 3), "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA operands hi.hi+hi.lo+lo.hi, f32 accumulate, f32 storage)",
+                      "bf16": "bf16 (MFMA operands; f32 accumulate, f32 storage)"}[args.precision], "data": "synthetic",
             "config": {"workload": "configs[1]: 1xMI355X, batch %d per GPU, 4-modality %d^3 synthetic BraTS patches; "
                                    "fwd + softmax_dice + 4 sub-region/edge losses + bwd + Adam(amsgrad); random-init weights, dropout on"
                                    % (args.batch, args.size),
-                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "arithmetic": "fp32 in / fp32 MFMA accumulate"},
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "precision": args.precision, "graph": not args.eager},
             "final_loss": round(final_loss, 5), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 2),
             "end_to_end": {"tflops": round(value * FLOP_PER_TRAIN_VOLUME * (args.size / 128.0) ** 3 / 1e12, 2),
-                           "frac_fp32_mfma_peak": round(value * FLOP_PER_TRAIN_VOLUME * (args.size / 128.0) ** 3 / 1e12 / world / FP32_MFMA_PEAK_TFLOPS, 4)},
+                           "frac_mfma_peak_for_mode": round(value * FLOP_PER_TRAIN_VOLUME * (args.size / 128.0) ** 3 / 1e12 / world / MFMA_PEAK_TFLOPS[args.precision], 4)},
         }
-        out["roofline"] = dominant_kernel_roofline(dev)
+        out["roofline"] = dominant_kernel_roofline(dev, args.precision)
         log("roofline leg done: %s" % json.dumps(out["roofline"]))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
