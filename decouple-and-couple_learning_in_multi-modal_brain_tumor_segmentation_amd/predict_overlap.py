@@ -1,0 +1,55 @@
+"""Sliding-window inference -- counterpart of the hot-path part of the reference ``predict_overlap.py``
+(BASELINE.json configs[3]: full 240x240x155 volume on one MI355X).
+
+``tailor_and_concat`` (predict_overlap.py:31-58): eight fixed 128^3 windows over a [B,4,240,240,>=155] volume
+(H, W starts {0, 112}, D starts {0, 27}) and hard-overwrite stitching -- INCLUDING the reference's depth-axis quirk
+(`y[..., 128:155] = window(27:155)[..., 96:123]`, i.e. voxels 123..149 land at 128..154), reproduced
+for parity.  The reference runs the eight windows as eight sequential B=1 forwards; here they are independent samples of
+one batch, so they go through the kernels as ONE batch-8 forward.
+
+``validate_softmax`` (predict_overlap.py:103-171) minus file I/O (nibabel / imageio are not hot-path): argmax over
+classes and the WT / TC / ET Dice of ``utils.tools.softmax_output_dice``.
+"""
+import torch
+
+from utils import tools
+
+WINDOWS = [(0, 0, 0), (0, 112, 0), (112, 0, 0), (112, 112, 0), (0, 0, 27), (0, 112, 27), (112, 0, 27), (112, 112, 27)]
+
+
+def tailor_and_concat(x, missing_modal, model, target=None, batched=True):
+    """x: [B,4,240,240,D>=155].  Returns the stitched probability volume [B,4,240,240,155]."""
+    wins = [x[..., a:a + 128, b:b + 128, c:c + 128] for a, b, c in WINDOWS]
+    if batched:
+        nb = x.shape[0]
+        out = model(torch.cat(wins, dim=0), missing_modal)[0]
+        t = [out[i * nb:(i + 1) * nb] for i in range(8)]
+    else:
+        t = [model(w, missing_modal)[0] for w in wins]
+    y = x.clone()                       # the reference relies on 4 modalities == 4 classes (predict_overlap.py:43)
+    y[..., :128, :128, :128] = t[0]
+    y[..., :128, 128:240, :128] = t[1][..., :, 16:128, :]
+    y[..., 128:240, :128, :128] = t[2][..., 16:128, :, :]
+    y[..., 128:240, 128:240, :128] = t[3][..., 16:128, 16:128, :]
+    y[..., :128, :128, 128:155] = t[4][..., 96:123]
+    y[..., :128, 128:240, 128:155] = t[5][..., :, 16:128, 96:123]
+    y[..., 128:240, :128, 128:155] = t[6][..., 16:128, :, 96:123]
+    y[..., 128:240, 128:240, 128:155] = t[7][..., 16:128, 16:128, 96:123]
+    return y[..., :155]
+
+
+@torch.no_grad()
+def validate_softmax(x, target, model, deterministic=True):
+    """One subject: stitched probabilities -> label map (argmax; class 3 stands for BraTS label 4) -> [WT, TC, ET] Dice.
+    ``deterministic`` zeroes the stem dropout that the reference leaves on in eval mode."""
+    model.eval()
+    saved = model.Unet_list.InitConv.dropout
+    if deterministic:
+        model.Unet_list.InitConv.dropout = 0.0
+    try:
+        prob = tailor_and_concat(x, None, model)
+    finally:
+        model.Unet_list.InitConv.dropout = saved
+    seg = prob.argmax(1)
+    dice = tools.softmax_output_dice(seg, target[..., :155]) if target is not None else None
+    return seg, prob, dice

@@ -141,3 +141,21 @@ def test_training_step_updates_weights(hip):
         opt.step()
         losses.append(float(loss))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_sliding_window_predictor_matches_oracle_stitching(hip):
+    """predict_overlap.tailor_and_concat (8 windows, incl. the D-axis stitch offset): batched-8 HIP forward vs the oracle's
+    stitching of per-window HIP forwards, and window 0 vs the CPU oracle model."""
+    import predict_overlap as po
+    m = _model().eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 4, 240, 240, 155, generator=g)
+    with torch.no_grad():
+        y = po.tailor_and_concat(x.to(DEV), None, m).cpu()
+        ref = rm.tailor_and_concat(x, lambda w: m(w.to(DEV), None)[0].cpu())
+        assert y.shape == (1, 4, 240, 240, 155)
+        assert float((y - ref).abs().max()) < 1e-5
+        w0 = rm.forward(syn.det_state_dict(rm.param_shapes()), x[..., :128, :128, :128])[0]
+    assert float((y[..., :128, :128, :128] - w0).abs().max()) < 1e-3
+    seg, prob, dice = po.validate_softmax(x.to(DEV), torch.randint(0, 4, (1, 240, 240, 155)).to(DEV), m)
+    assert seg.shape == (1, 240, 240, 155) and len(dice) == 3
