@@ -62,6 +62,8 @@ class HipBackend:
         if not torch.cuda.is_available():
             raise _lib.CwfError("no GPU visible: the cwf kernels are gfx950-only and there is no CPU fallback")
         self._ws = {}
+        self._arena = {}
+        self._arena_off = {}
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -74,12 +76,40 @@ class HipBackend:
             raise _lib.CwfError("%s failed with status %d" % (name, rc))
 
     def workspace(self, key, nfloats, device):
-        """Grow-only scratch buffers (wgrad partial slabs).  Stream-ordered reuse is safe: one stream."""
-        buf = self._ws.get((key, device))
+        """Grow-only scratch buffers (wgrad partial slabs), one per (device, stream): reuse is stream-ordered."""
+        k = (key, device, torch.cuda.current_stream().cuda_stream)
+        buf = self._ws.get(k)
         if buf is None or buf.numel() < nfloats:
             buf = torch.empty(int(nfloats), dtype=_f32, device=device)
-            self._ws[(key, device)] = buf
+            self._ws[k] = buf
         return buf
+
+    # Small f64 accumulators (InstanceNorm / loss sums) come from ONE arena that is zeroed once per step (begin_step, called
+    # by the model's forward) instead of ~340 separate fill launches.  Regions are handed out once per step and never reused
+    # within it; the arena is sized for forward + backward of a step with a generous margin and falls back to torch.zeros.
+    ARENA_DOUBLES = 1 << 20
+
+    def begin_step(self, device):
+        a = self._arena.get(device)
+        if a is None:
+            a = torch.zeros(self.ARENA_DOUBLES, dtype=torch.float64, device=device)
+            self._arena[device] = a
+        else:
+            a.zero_()
+        self._arena_off[device] = 0
+
+    def _zeros_f64(self, shape, device):
+        n = 1
+        for s in shape:
+            n *= s
+        device = torch.device(device)
+        a = self._arena.get(device)
+        if a is not None:
+            off = self._arena_off[device]
+            if off + n <= a.numel():
+                self._arena_off[device] = off + ((n + 1) // 2) * 2         # keep 16-byte alignment
+                return a[off:off + n].view(shape)
+        return torch.zeros(shape, dtype=torch.float64, device=device)
 
     # ------------------------------------------------------------------ K1
     def conv(self, op, x, wpk, bias, cout, in_scale=None, in_shift=None, slope=1.0, residual=None, out_scale=None,
@@ -141,7 +171,7 @@ class HipBackend:
 
     # ------------------------------------------------------------------ K3
     def new_stats(self, n, c, device):
-        return torch.zeros((n, c, 2), dtype=torch.float64, device=device)
+        return self._zeros_f64((n, c, 2), device)
 
     def in_finalize(self, stats, nvox, eps=1e-5):
         n, c, _ = stats.shape
@@ -341,7 +371,7 @@ class HipBackend:
         """prob [N,D,H,W,C] dense channels-last, label int64 [N,D,H,W] -> (loss [1], coef [N,C,4])"""
         n, d, h, w, c = prob.shape
         v = d * h * w
-        sums = torch.zeros((n, c, 4), dtype=torch.float64, device=prob.device)
+        sums = self._zeros_f64((n, c, 4), prob.device)
         self._call("cwf_dice_ce_sums", prob.data_ptr(), label.data_ptr(), posmask, sums.data_ptr(), n, v, c, self._stream())
         loss = torch.empty(1, dtype=_f32, device=prob.device)
         coef = torch.empty((n, c, 4), dtype=_f32, device=prob.device)

@@ -77,6 +77,8 @@ class ClsWiseFormer(nn.Module):
         self.forced_index = None      # dict name -> int tensor [B,k]: teacher-forced top-k selections
         self.collect_aux = False
         self.aux = {}
+        self.parallel_regions = True  # run the three sub-region pipelines on parallel HIP streams
+        self._streams = None
 
     # ------------------------------------------------------------------------------------------------
     def _select(self, feats, score_tok, head, name):
@@ -90,45 +92,69 @@ class ClsWiseFormer(nn.Module):
             self.aux[name] = idx
         return seq, idx
 
+    def _region(self, r, k, x23, x4):
+        """Everything that belongs to ONE sub-region (label 1 / 2 / 4): decoupler convs, mid heads, token selection,
+        intra-region coupler, scatter + gate, supervision heads.  The three regions are independent until the fusion."""
+        f, s = getattr(self, "conv_mid_fea_%d" % k)(x23, want_stats=True)           # edge decoupler (:284-296)
+        ef = CF.norm_act_add(f, s, 0.01)
+        f, s = getattr(self, "conv_semantic_%d" % k)(x4, want_stats=True)            # Anatomy-induced Region Decoupler (:314-324)
+        sf = CF.norm_act_add(f, s, 0.01)
+        mid_sup = self.mid_supervise_label.head(k, sf)                               # :332
+        mid_edge = self.mid_edge_supervise_label.head(k, ef)                         # :333
+        sem_size, edge_size = tuple(sf.shape[1:4]), tuple(ef.shape[1:4])
+        E = CF.window_to_tokens(ef, self.edge_patch_size)        # [B,Ne,512]  :341
+        S = CF.window_to_tokens(sf, self.patch_size)             # [B,Ns,512]  :342
+        e_tok, s_tok = getattr(self, "e_token_" + r), getattr(self, "s_token_" + r)
+        edge_seq, idx_e = self._select(E, e_tok, e_tok, r + "_edge")           # :345-350
+        sem_supp, _ = self._select(S, e_tok, s_tok, r + "_sem_supp")           # :352-357 scored by e_tok, headed by s_tok
+        sem_seq, idx_s = self._select(S, s_tok, s_tok, r + "_sem")             # :360-367
+        edge_supp, _ = self._select(E, s_tok, e_tok, r + "_edge_supp")         # :370-376 scored by s_tok, headed by e_tok
+        res = getattr(self, "transformer_" + r)(edge_seq, sem_supp, sem_seq, edge_supp)     # :379  [B,258,512]
+        n1 = edge_seq.shape[1]
+        gated_e, _ = CF.scatter_gate(E, idx_e, res[:, 1:n1], res[:, 0:1])                   # :467,481
+        gated_s, scat_s = CF.scatter_gate(S, idx_s, res[:, n1 + 1:2 * n1], res[:, n1:n1 + 1])   # :477,484
+        sup_edge = CF.tokens_to_window(gated_e, edge_size, self.edge_feature_n, self.edge_patch_size)
+        sup_sem = CF.tokens_to_window(gated_s, sem_size, self.item_feature_n, self.patch_size)
+        sup = self.supervise_label.head(k, sup_sem)                                  # :545
+        edge = self.edge_supervise_label.head(k, sup_edge)                           # :546
+        return dict(mid_sup=mid_sup, mid_edge=mid_edge, sup=sup, edge=edge, sem_token=res[:, n1:n1 + 1], sem_after=scat_s,
+                    sem_size=sem_size)
+
     def encode(self, x, missing_modal=None):
         x1, x2, x3, x4 = self.Unet_list(x)
-
-        # edge decoupler (cls_wise_former.py:284-296)
-        x2d, _ = self.conv_64_to_32(x2)
+        x2d, _ = self.conv_64_to_32(x2)                           # :284
         x23 = CF.cat_channels(x2d, x3)
-        edge_f, sem_f = [], []
-        for k in (1, 2, 4):
-            f, s = getattr(self, "conv_mid_fea_%d" % k)(x23, want_stats=True)
-            edge_f.append(CF.norm_act_add(f, s, 0.01))
-        # Anatomy-induced Region Decoupler (:314-324)
-        for k in (1, 2, 4):
-            f, s = getattr(self, "conv_semantic_%d" % k)(x4, want_stats=True)
-            sem_f.append(CF.norm_act_add(f, s, 0.01))
 
-        mid_sup = self.mid_supervise_label(*sem_f)                   # :332
-        mid_edge = self.mid_edge_supervise_label(*edge_f)            # :333
+        # The three sub-region pipelines are made of small, latency-bound kernels (16^3 / 32^3 grids, 129-token GEMMs):
+        # each runs on its own HIP stream so they overlap (under hipGraph capture they become parallel branches).
+        outs = [None, None, None]
+        use_streams = self.parallel_regions and x.is_cuda
+        if use_streams:
+            main = torch.cuda.current_stream()
+            if self._streams is None:
+                self._streams = [torch.cuda.Stream(device=x.device) for _ in REGIONS]
+            for t in (x23, x4):
+                for st in self._streams:
+                    t.record_stream(st)
+            for i, (r, k) in enumerate(zip(REGIONS, (1, 2, 4))):
+                st = self._streams[i]
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    outs[i] = self._region(r, k, x23, x4)
+            for i, st in enumerate(self._streams):
+                main.wait_stream(st)
+                for v in outs[i].values():
+                    if torch.is_tensor(v):
+                        v.record_stream(main)
+        else:
+            for i, (r, k) in enumerate(zip(REGIONS, (1, 2, 4))):
+                outs[i] = self._region(r, k, x23, x4)
 
-        sem_size, edge_size = tuple(sem_f[0].shape[1:4]), tuple(edge_f[0].shape[1:4])
-        sup_sem, sup_edge, sem_tokens, sem_after = [], [], [], []
-        for r, ef, sf in zip(REGIONS, edge_f, sem_f):
-            E = CF.window_to_tokens(ef, self.edge_patch_size)        # [B,Ne,512]  :341
-            S = CF.window_to_tokens(sf, self.patch_size)             # [B,Ns,512]  :342
-            e_tok, s_tok = getattr(self, "e_token_" + r), getattr(self, "s_token_" + r)
-            edge_seq, idx_e = self._select(E, e_tok, e_tok, r + "_edge")           # :345-350
-            sem_supp, _ = self._select(S, e_tok, s_tok, r + "_sem_supp")           # :352-357 scored by e_tok, headed by s_tok
-            sem_seq, idx_s = self._select(S, s_tok, s_tok, r + "_sem")             # :360-367
-            edge_supp, _ = self._select(E, s_tok, e_tok, r + "_edge_supp")         # :370-376 scored by s_tok, headed by e_tok
-            res = getattr(self, "transformer_" + r)(edge_seq, sem_supp, sem_seq, edge_supp)     # :379  [B,258,512]
-            n1 = edge_seq.shape[1]
-            gated_e, _ = CF.scatter_gate(E, idx_e, res[:, 1:n1], res[:, 0:1])                   # :467,481
-            gated_s, scat_s = CF.scatter_gate(S, idx_s, res[:, n1 + 1:2 * n1], res[:, n1:n1 + 1])   # :477,484
-            sup_edge.append(CF.tokens_to_window(gated_e, edge_size, self.edge_feature_n, self.edge_patch_size))
-            sup_sem.append(CF.tokens_to_window(gated_s, sem_size, self.item_feature_n, self.patch_size))
-            sem_tokens.append(res[:, n1:n1 + 1])
-            sem_after.append(scat_s)
-
-        sup = self.supervise_label(*sup_sem)                          # :545
-        edge = self.edge_supervise_label(*sup_edge)                   # :546
+        pick = lambda key: {r: o[key] for r, o in zip(REGIONS, outs)}
+        sup, edge, mid_sup, mid_edge = pick("sup"), pick("edge"), pick("mid_sup"), pick("mid_edge")
+        sem_tokens = [o["sem_token"] for o in outs]
+        sem_after = [o["sem_after"] for o in outs]
+        sem_size = outs[0]["sem_size"]
 
         # Mutual Cross-region Coupler (:549-579): post-scatter UN-gated semantic tokens are fused
         f_tok = CF.add(CF.add(sem_tokens[0], sem_tokens[1]), sem_tokens[2])
@@ -150,6 +176,7 @@ class ClsWiseFormer(nn.Module):
         if d % 16 or h % 16 or w % 16 or (d // 8) * (h // 8) * (w // 8) // 4 < 1:
             raise ValueError("D, H, W must be multiples of 16 (got %d,%d,%d)" % (d, h, w))
         self.aux = {}
+        backend().begin_step(x.device)
         self._packer.refresh()
         xc = x.to(torch.float32).permute(0, 2, 3, 4, 1).contiguous()  # NDHWC
         x1, x2, x3, xb, sup, edge, mid_sup, mid_edge = self.encode(xc, missing_modal)

@@ -17,6 +17,10 @@ class _Heads(nn.Module):
 
 
 class SuperviseLabel(_Heads):
+    def head(self, k, x):
+        """One sub-region's head (k in {1,2,4})."""
+        return self._head(getattr(self, "supervise_label_%d" % k), getattr(self, "down_label_%d" % k), x)
+
     def __init__(self, item_future_num):
         super().__init__()
         for k in (1, 2, 4):
@@ -31,6 +35,9 @@ class SuperviseLabel(_Heads):
 
 
 class EdgeSuperviseLabel(_Heads):
+    def head(self, k, x):
+        return self._head(getattr(self, "edge_supervise_label_%d" % k), getattr(self, "edge_down_label_%d" % k), x)
+
     def __init__(self, item_future_num):
         super().__init__()
         for k in (1, 2, 4):

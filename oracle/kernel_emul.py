@@ -100,6 +100,9 @@ class EmulBackend:
             gw, gb = torch.autograd.grad(y, (w, b), dy.contiguous())
         return gw.reshape(-1), (gb if has_bias_map else None)
 
+    def begin_step(self, device):
+        pass
+
     def gather_batched(self, table, nlayers, max_n, split_bf16=False):
         pass    # packed buffers are unused by the emulation
 
