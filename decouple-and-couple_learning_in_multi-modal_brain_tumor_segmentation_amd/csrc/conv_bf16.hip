@@ -10,6 +10,7 @@
 // Packed weights: [class][ci_chunk16][tap pair][co_tile16][lane64][hi 8 | lo 8] bf16 (cwf_gather_split_bf16).
 // Geometry, tiling, epilogue (bias / residual / out_scale / InstanceNorm statistics) are those of conv_mfma.hip.
 #include "common.h"
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -18,14 +19,24 @@ struct ConvArgsB {
   const float* x; const uint4* wpk; const float* bias; float* y;
   const float* in_scale; const float* in_shift; float in_slope;
   const float* residual; int r_ldc; const float* out_scale; double* stats;
-  unsigned long long* diag;
+  unsigned long long* diag; int diag_mode;
 };
 
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-  const __bf16 x = (__bf16)a, y = (__bf16)b;
-  return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {          // one v_cvt_pk_bf16_f32
+  const f32x2_t f = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
 }
 __device__ __forceinline__ float bf16_round(float a) { return (float)(__bf16)a; }
+// split two floats into packed bf16 hi and lo (lo = bf16(v - hi)):  cvt_pk, shl/and, 2 sub, cvt_pk
+__device__ __forceinline__ void split_bf16(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = pack_bf16(a, b);
+  const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+  lo = pack_bf16(a - ha, b - hb);
+}
+// branch-free (Leaky)ReLU / identity for slope in [0,1]: max(v, slope*v)
+__device__ __forceinline__ float act01(float v, float slope) { return fmaxf(v, v * slope); }
 
 // Stage one 16-channel chunk as bf16 hi (and lo) images [voxel][16].
 template <bool X3>
@@ -240,9 +251,12 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_sp = g.tiles_d * g.tiles_h * g.tiles_w;
-  const int first = blockIdx.x;
+  // Workgroup b owns the CONTIGUOUS tile range [b*chunk, (b+1)*chunk): consecutive tiles are spatial neighbours, so the
+  // halo rows they share are re-read from this XCD's L2 instead of the fabric (a 256-tile stride put neighbours on other XCDs).
+  const int chunk = (total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int first = blockIdx.x * chunk;
   if (first >= total_tiles) return;                    // uniform for the whole workgroup
-  const int niter = (total_tiles - first + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int niter = min(chunk, total_tiles - first);
 
   if (wave < 4) {
     // =============================================================== MFMA waves
@@ -284,7 +298,7 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
 
     unsigned long long d_bar = 0, d_mfma = 0, d_epi = 0;
     for (int it = 0; it < niter; ++it) {
-      const int tile = first + it * (int)gridDim.x;
+      const int tile = first + it;
       CWF_STAMP(t0);
       // Raw barrier: __syncthreads() would add s_waitcnt vmcnt(0) and make this wave wait for its own output stores.
       asm volatile("s_barrier" ::: "memory");            // buffer it&1 is complete
@@ -338,19 +352,35 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
         float* yb = a.y + vox0 * g.y_ldc;
         const float* rb = a.residual ? a.residual + vox0 * a.r_ldc : nullptr;
         const float osc = (a.out_scale && r < g.Cout) ? a.out_scale[(int64_t)n * g.Cout + r] : 1.f;
-        const bool full = (oh0 + C16_TH <= g.Ho) && (ow0 + 16 <= g.Wo) && r < g.Cout;
+        const bool full = (oh0 + C16_TH <= g.Ho) && (ow0 + 16 <= g.Wo) && g.Cout == 16;     // wave-uniform
+        if (full) {
+          // branch-free fast path (interior tiles, 16 output channels): 16 stores at uniform-base + lane-offset addresses
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+          for (int m = 0; m < 4; ++m) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const bool ok = full || (r < g.Cout && oh0 + m < g.Ho && ow0 + kq * 4 + i < g.Wo);
-            if (!ok) continue;
-            const int eo = m * g.Wo + i;                                    // uniform part, in voxels
-            float v = acc[m][i] + bv;
-            if (rb) v += rb[eo * a.r_ldc + rlane];
-            v *= osc;
-            yb[eo * g.y_ldc + ylane] = v;
-            s1 += v; s2 += v * v;
+            for (int i = 0; i < 4; ++i) {
+              const int eo = m * g.Wo + i;
+              float v = acc[m][i] + bv;
+              if (rb) v += rb[eo * a.r_ldc + rlane];
+              v *= osc;
+              if (!(DIAG && (a.diag_mode & 1))) yb[eo * g.y_ldc + ylane] = v;
+              s1 += v; s2 += v * v;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const bool ok = r < g.Cout && oh0 + m < g.Ho && ow0 + kq * 4 + i < g.Wo;
+              if (!ok) continue;
+              const int eo = m * g.Wo + i;
+              float v = acc[m][i] + bv;
+              if (rb) v += rb[eo * a.r_ldc + rlane];
+              v *= osc;
+              yb[eo * g.y_ldc + ylane] = v;
+              s1 += v; s2 += v * v;
+            }
           }
         }
       }
@@ -380,88 +410,119 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
       rel[i] = (idd * HW + ih * g.Wi + iw) * g.x_ldc + c;
     }
     const bool last_slot_ok = (lt >> 2) + 64 * (C16_SLOTS - 1) < C16_NVOX;
-    float4 pre[C16_SLOTS];
-    unsigned pre_inb = 0;
-    auto fetch = [&](int tile) {
-      const int n = tile / tiles_sp; int rem = tile - n * tiles_sp;
+    // Two tiles of loads are kept in flight in two register sets (2 x 11 float4): the ~4 us latency of this halo access
+    // pattern exceeds one tile time (measured: with a one-tile distance the tile time equilibrates at the latency).
+    // Everything below is STRAIGHT-LINE per tile (out-of-range slots load a dummy address and are zeroed by a select): any
+    // per-slot branch makes the compiler fall back from counted s_waitcnt vmcnt(N) to vmcnt(0), which serialises the pipeline.
+    float4 pre[2][C16_SLOTS];
+    unsigned pre_inb[2] = {0u, 0u};
+    __builtin_amdgcn_s_setprio(1);                       // loaders are the critical path: win VALU/VMEM issue arbitration
+    struct TileOrg { const float* base; bool interior; int id0, ih0, iw0, n; };
+    auto origin = [&](int tile) {
+      TileOrg o;
+      o.n = tile / tiles_sp; int rem = tile - o.n * tiles_sp;
       const int tile_w = rem % g.tiles_w; rem /= g.tiles_w;
       const int tile_h = rem % g.tiles_h; const int tile_d = rem / g.tiles_h;
-      const int id0 = tile_d * C16_TD - 1, ih0 = tile_h * C16_TH - 1, iw0 = tile_w * 16 - 1;
-      const float* base = a.x + ((((int64_t)n * g.Di + id0) * g.Hi + ih0) * g.Wi + iw0) * g.x_ldc;   // uniform
-      const bool interior = id0 >= 0 && id0 + C16_ID <= g.Di && ih0 >= 0 && ih0 + C16_IH <= g.Hi && iw0 >= 0 && iw0 + C16_IW <= g.Wi;
-      pre_inb = 0;
+      o.id0 = tile_d * C16_TD - 1; o.ih0 = tile_h * C16_TH - 1; o.iw0 = tile_w * 16 - 1;
+      o.base = a.x + ((((int64_t)o.n * g.Di + o.id0) * g.Hi + o.ih0) * g.Wi + o.iw0) * g.x_ldc;
+      o.interior = o.id0 >= 0 && o.id0 + C16_ID <= g.Di && o.ih0 >= 0 && o.ih0 + C16_IH <= g.Hi && o.iw0 >= 0 && o.iw0 + C16_IW <= g.Wi;
+      return o;
+    };
+    const bool lane_ok = cval && !(DIAG && (a.diag_mode & 2));
+    // issue the 11 loads of tile `o` into register set S; returns the in-bounds mask.  No branches inside.
+    auto issue = [&](const TileOrg& o, auto S) -> unsigned {
+      constexpr int SET = decltype(S)::value;
+      unsigned inb = 0;
+      if (o.interior) {                                  // wave-uniform; both arms are straight-line
 #pragma unroll
-      for (int i = 0; i < C16_SLOTS; ++i) {
-        pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        bool ok = cval && (i < C16_SLOTS - 1 || last_slot_ok);
-        if (!interior) {                                 // wave-uniform branch: border tiles only
+        for (int i = 0; i < C16_SLOTS; ++i) {
+          const bool ok = lane_ok && (i < C16_SLOTS - 1 || last_slot_ok);
+          const float* p = ok ? o.base + rel[i] : a.x;
+          pre[SET][i] = *reinterpret_cast<const float4*>(p);
+          inb |= ok ? (1u << i) : 0u;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < C16_SLOTS; ++i) {
           const int v = (lt >> 2) + 64 * i;
           const int iw = v % C16_IW, t2 = v / C16_IW;
           const int ih = t2 % C16_IH, idd = t2 / C16_IH;
-          const int gd = id0 + idd, gh = ih0 + ih, gw = iw0 + iw;
-          ok = ok && gd >= 0 && gd < g.Di && gh >= 0 && gh < g.Hi && gw >= 0 && gw < g.Wi;
+          const int gd = o.id0 + idd, gh = o.ih0 + ih, gw = o.iw0 + iw;
+          const bool ok = lane_ok && (i < C16_SLOTS - 1 || last_slot_ok) &&
+                          (unsigned)gd < (unsigned)g.Di && (unsigned)gh < (unsigned)g.Hi && (unsigned)gw < (unsigned)g.Wi;
+          const float* p = ok ? o.base + rel[i] : a.x;
+          pre[SET][i] = *reinterpret_cast<const float4*>(p);
+          inb |= ok ? (1u << i) : 0u;
         }
-        if (ok) { pre[i] = *reinterpret_cast<const float4*>(base + rel[i]); pre_inb |= 1u << i; }
       }
+      return inb;
     };
-    auto commit = [&](int tile, int buf) {               // registers -> (norm, act, bf16 split) -> LDS buffer
+    // convert register set S (tile tc) into LDS buffer `buf`
+    auto convert = [&](int tc, int buf, auto S) {
+      constexpr int SET = decltype(S)::value;
       float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
       if (has_norm && cval) {
-        const int n = tile / tiles_sp;
+        const int n = tc / tiles_sp;
         sc = *reinterpret_cast<const float4*>(a.in_scale + (int64_t)n * g.Cin + c);
         sh = *reinterpret_cast<const float4*>(a.in_shift + (int64_t)n * g.Cin + c);
       }
+      const float sl = (has_norm || slope != 1.f) ? slope : 1.f;
+      const unsigned inb = pre_inb[SET];
       unsigned short* dh = lds + buf * BUF + (lt >> 2) * 16 + q * 4;
       unsigned short* dl = dh + IMG;
 #pragma unroll
       for (int i = 0; i < C16_SLOTS; ++i) {
-        if (i == C16_SLOTS - 1 && !last_slot_ok) continue;
-        float4 val = pre[i];
-        if ((has_norm || slope != 1.f) && ((pre_inb >> i) & 1u)) {
-          val.x = cwf_act(val.x * sc.x + sh.x, slope); val.y = cwf_act(val.y * sc.y + sh.y, slope);
-          val.z = cwf_act(val.z * sc.z + sh.z, slope); val.w = cwf_act(val.w * sc.w + sh.w, slope);
-        }
-        uint2 h; h.x = pack_bf16(val.x, val.y); h.y = pack_bf16(val.z, val.w);
+        if (i == C16_SLOTS - 1 && !last_slot_ok) continue;         // (whole-quad predicate, not per slot: cheap)
+        const float4 val = pre[SET][i];
+        const bool was = (inb >> i) & 1u;
+        // zero padding is applied AFTER the activation: out-of-range voxels stay exactly 0
+        const float v0 = was ? cwf_act(val.x * sc.x + sh.x, sl) : 0.f, v1 = was ? cwf_act(val.y * sc.y + sh.y, sl) : 0.f;
+        const float v2 = was ? cwf_act(val.z * sc.z + sh.z, sl) : 0.f, v3 = was ? cwf_act(val.w * sc.w + sh.w, sl) : 0.f;
+        uint2 h, l;
+        if (X3) { split_bf16(v0, v1, h.x, l.x); split_bf16(v2, v3, h.y, l.y); }
+        else { h.x = pack_bf16(v0, v1); h.y = pack_bf16(v2, v3); }
         *reinterpret_cast<uint2*>(dh + i * 64 * 16) = h;
-        if (X3) {
-          uint2 l;
-          l.x = pack_bf16(val.x - bf16_round(val.x), val.y - bf16_round(val.y));
-          l.y = pack_bf16(val.z - bf16_round(val.z), val.w - bf16_round(val.w));
-          *reinterpret_cast<uint2*>(dl + i * 64 * 16) = l;
-        }
+        if (X3) *reinterpret_cast<uint2*>(dl + i * 64 * 16) = l;
       }
     };
-    const int G = (int)gridDim.x;
-    unsigned long long d_bar = 0, d_wait = 0, d_commit = 0, d_fetch = 0;
-    fetch(first);
-    commit(first, 0);
-    if (niter > 1) fetch(first + G);
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    unsigned long long d_bar = 0, d_commit = 0;
+    // prologue: tile 0 -> set 0 -> LDS buffer 0; then tiles 1 (set 1) and 2 (set 0) in flight
+    pre_inb[0] = issue(origin(first), S0{});
+    convert(first, 0, S0{});
+    if (niter > 1) pre_inb[1] = issue(origin(first + 1), S1{});
+    if (niter > 2) pre_inb[0] = issue(origin(first + 2), S0{});
+    // iteration it: tile it+1 sits in set (it+1)&1 -> LDS buffer (it+1)&1; that set is then refilled with tile it+3
     for (int it = 0; it < niter; ++it) {
       CWF_STAMP(t0);
-      // LDS writes done -> barrier.  Raw form: __syncthreads() would also wait (vmcnt(0)) for the prefetch in flight.
+      // LDS writes done -> barrier.  Raw form: __syncthreads() would also wait (vmcnt(0)) for the prefetches in flight.
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // buffer it&1 handed over; buffer (it+1)&1 is free
       CWF_STAMP(t1);
       if (it + 1 < niter) {
-        if (DIAG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        CWF_STAMP(t2);
-        commit(first + (it + 1) * G, (it + 1) & 1);
-        if (DIAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        CWF_STAMP(t3);
-        if (it + 2 < niter) fetch(first + (it + 2) * G);
-        CWF_STAMP(t4);
-        if (DIAG) { d_wait += t2 - t1; d_commit += t3 - t2; d_fetch += t4 - t3; }
+        if ((it + 1) & 1) {
+          convert(first + it + 1, 1, S1{});
+          if (it + 3 < niter) pre_inb[1] = issue(origin(first + it + 3), S1{});
+        } else {
+          convert(first + it + 1, 0, S0{});
+          if (it + 3 < niter) pre_inb[0] = issue(origin(first + it + 3), S0{});
+        }
       }
-      if (DIAG) d_bar += t1 - t0;
+      if (DIAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      CWF_STAMP(t2);
+      if (DIAG) { d_bar += t1 - t0; d_commit += t2 - t1; }
     }
     if (DIAG && a.diag && lane == 0) {
       unsigned long long* o = a.diag + ((int64_t)blockIdx.x * 8 + wave) * 4;
-      o[0] = d_bar; o[1] = d_wait; o[2] = d_commit; o[3] = d_fetch;
+      o[0] = d_bar; o[1] = 0; o[2] = d_commit; o[3] = 0;
     }
   }
 }
 
 static unsigned long long* g_conv16_diag = nullptr;
-extern "C" void cwf_debug_conv16_diag(unsigned long long* buf) { g_conv16_diag = buf; }   // [256][8][4] u64, or NULL = off
+static int g_conv16_diag_mode = 0;
+extern "C" void cwf_debug_conv16_diag(unsigned long long* buf) { g_conv16_diag = buf; }
+extern "C" void cwf_debug_conv16_mode(int m) { g_conv16_diag_mode = m; }   // diagnostic builds: 1 = no stores, 2 = no loads   // [256][8][4] u64, or NULL = off
 
 template <bool X3, bool DIAG>
 static int launch_conv16_impl(ConvArgsB a, hipStream_t st) {
@@ -473,7 +534,7 @@ static int launch_conv16_impl(ConvArgsB a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv16_kernel<X3, DIAG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  a.diag = DIAG ? g_conv16_diag : nullptr;
+  a.diag = DIAG ? g_conv16_diag : nullptr; a.diag_mode = g_conv16_diag_mode;
   int grid = 256; if (grid > total) grid = total;          // one 8-wave workgroup per CU
   hipLaunchKernelGGL((conv16_kernel<X3, DIAG>), dim3(grid), dim3(512), lds, st, a, total);
   CWF_LAUNCH_CHECK();

@@ -37,6 +37,15 @@ if os.environ.get("CWF_DIAG"):
     diag = torch.zeros((256, 8, 4), dtype=torch.int64, device=dev)
     K.lib.cwf_debug_conv16_diag.argtypes = [ctypes.c_void_p]; K.lib.cwf_debug_conv16_diag.restype = None
     K.lib.cwf_debug_conv16_diag(diag.data_ptr())
+    K.lib.cwf_debug_conv16_mode.argtypes = [ctypes.c_int]; K.lib.cwf_debug_conv16_mode.restype = None
+    for mode in (0, 1, 2, 3):
+        K.lib.cwf_debug_conv16_mode(mode)
+        run(); torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5): run()
+        e1.record(); torch.cuda.synchronize()
+        print("diag build, mode %d (1=no stores, 2=no loads, 3=neither): %.4f ms" % (mode, e0.elapsed_time(e1) / 5))
+    K.lib.cwf_debug_conv16_mode(0)
     run(); torch.cuda.synchronize()
     K.lib.cwf_debug_conv16_diag(None)
     d = diag.cpu().double()
