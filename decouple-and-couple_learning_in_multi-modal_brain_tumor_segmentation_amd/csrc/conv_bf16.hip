@@ -249,7 +249,8 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
   constexpr int BUF = IMG * (X3 ? 2 : 1);              // per buffer: hi image (+ lo image)
   unsigned short* lds = reinterpret_cast<unsigned short*>(lds4);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the role branch below is provably wave-uniform
   const int tiles_sp = g.tiles_d * g.tiles_h * g.tiles_w;
   // Workgroup b owns the CONTIGUOUS tile range [b*chunk, (b+1)*chunk): consecutive tiles are spatial neighbours, so the
   // halo rows they share are re-read from this XCD's L2 instead of the fabric (a 256-tile stride put neighbours on other XCDs).

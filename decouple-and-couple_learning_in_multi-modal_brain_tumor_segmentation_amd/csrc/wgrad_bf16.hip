@@ -9,6 +9,7 @@
 // X3 = true: x = xh + xl, dy = dh + dl -> xh.dh + xh.dl + xl.dh (fp32 accumulate);  X3 = false: xh.dh only.
 // Work split, persistent tile walk, partial-slab layout and the reduce step are those of wgrad_mfma.hip.
 #include "common.h"
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -211,13 +212,247 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgsB a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// wgrad16: weight gradient of the full-resolution 3x3x3 convolutions with <= 16 input and 16 output channels
+// (the conv16 layers).  Same producer / consumer structure as conv16_kernel (conv_bf16.hip), for the same measured reasons:
+//   * 8-wave persistent workgroups, one per CU, each owning a CONTIGUOUS range of 4x4x16 tiles;
+//   * waves 4-7 (loaders) keep two tiles of global loads in flight (x halo 6x6x18 + dy 4x4x16, fp32), apply the recomputed
+//     InstanceNorm + activation prologue to x, split both to bf16 hi/lo and fill the other LDS buffer -- straight-line code so
+//     that the compiler emits counted vmcnt waits;
+//   * waves 0-3 (MFMA) only do transposed LDS reads + MFMAs; wave w owns taps w, w+4, ... (slot 27 = bias row) and keeps its
+//     7 accumulators in registers across ALL tiles of the workgroup: no per-tile epilogue at all;
+//   * raw s_barrier (lgkmcnt only) hands the buffers over; one slab per workgroup at the end (reduced by cwf_wgrad_reduce).
+// ---------------------------------------------------------------------------------------------------
+#define W16_NVOX 648
+#define W16_LW 6                                        // loader waves (MFMA waves: 4) -> 640-thread workgroups
+#define W16_VPP (W16_LW * 16)                           // voxels staged per pass (4 threads per voxel)
+#define W16_XS ((W16_NVOX + W16_VPP - 1) / W16_VPP)     // 7 x staging slots per loader thread
+#define W16_DS ((256 + W16_VPP - 1) / W16_VPP)          // 3 dy staging slots per loader thread
+
+typedef __bf16 bf16x2_w __attribute__((ext_vector_type(2)));
+typedef float f32x2_w __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  const f32x2_w f = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_w));
+}
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = pk_bf16(a, b);
+  const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+  lo = pk_bf16(a - ha, b - hb);
+}
+
+template <bool X3>
+__global__ __launch_bounds__(256 + 64 * W16_LW) void wgrad16_kernel(const WgArgsB a, int total_tiles) {
+  extern __shared__ float4 lds4[];
+  const ConvGeom& g = a.g;
+  constexpr int XI = W16_NVOX * 16;                    // bf16 elements of one x image
+  constexpr int DI = 256 * 16;                         // bf16 elements of one dy image
+  constexpr int BUF = (XI + DI) * (X3 ? 2 : 1);        // per buffer: xh [xl] dh [dl]
+  unsigned short* lds = reinterpret_cast<unsigned short*>(lds4);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the role branch below is provably wave-uniform
+  const int tiles_sp = g.tiles_d * g.tiles_h * g.tiles_w;
+  const int chunk = (total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int first = blockIdx.x * chunk;
+  const int niter = first < total_tiles ? min(chunk, total_tiles - first) : 0;   // empty workgroups still write a zero slab
+
+  if (wave < 4) {
+    // =============================================================== MFMA waves
+    const int kq = lane >> 4;
+    const int bq = (lane & 15) >> 2, bp = lane & 3;
+    f32x4 acc[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
+    // lane-constant part of the transposed-read addresses (bf16 elements): block row bq (+4), column quad bp
+    const int tw0 = (kq & 1) * 8 + bq;
+    int tapo[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int t = wave + 4 * i;
+      tapo[i] = t < 27 ? (((t / 9) * 6 + (t / 3) % 3) * 18 + t % 3) * 16 : 0;
+    }
+    for (int it = 0; it < niter; ++it) {
+      asm volatile("s_barrier" ::: "memory");            // buffer it&1 is complete
+      const unsigned short* xh = lds + (it & 1) * BUF;
+      const unsigned short* xl = xh + XI;
+      const unsigned short* dh = xh + XI * (X3 ? 2 : 1);
+      const unsigned short* dl = dh + DI;
+#pragma unroll 2
+      for (int ks = 0; ks < 8; ++ks) {                   // 32 voxels per step = M-tiles (2ks, 2ks+1)
+        const int mt = 2 * ks + (kq >> 1);
+        const int vin = (((mt >> 2) * 6 + (mt & 3)) * 18 + tw0) * 16 + bp * 4;
+        const int vout = (mt * 16 + tw0) * 16 + bp * 4;
+        const bf16x8 bhf = tr_frag(dh + vout, dh + vout + 4 * 16);
+        bf16x8 blf;
+        if (X3) blf = tr_frag(dl + vout, dl + vout + 4 * 16);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          const int t = wave + 4 * i;
+          if (t > 27) continue;                          // wave-uniform (waves 0-2 have 7 real taps, wave 3 has 6 + bias)
+          if (t == 27) {
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bhf, acc[i], 0, 0, 0);
+            if (X3) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, blf, acc[i], 0, 0, 0);
+          } else {
+            const bf16x8 ahf = tr_frag(xh + vin + tapo[i], xh + vin + tapo[i] + 4 * 16);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahf, bhf, acc[i], 0, 0, 0);
+            if (X3) {
+              const bf16x8 alf = tr_frag(xl + vin + tapo[i], xl + vin + tapo[i] + 4 * 16);
+              acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahf, blf, acc[i], 0, 0, 0);
+              acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alf, bhf, acc[i], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    // one slab per workgroup: [tap slot 0..27][lane][4]   (chunk 0, group 0, CG = 1)
+    float4* out = reinterpret_cast<float4*>(a.partial + (int64_t)blockIdx.x * a.slab_floats);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int t = wave + 4 * i;
+      if (t > 27) continue;
+      out[(int64_t)t * 64 + lane] = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+    }
+  } else {
+    // =============================================================== loader waves
+    const int lt = tid - 256;
+    const int q = lt & 3, c = q * 4;
+    const bool cval = c < g.Cin;
+    const bool has_norm = a.in_scale != nullptr;
+    const float slope = a.in_slope;
+    const float sl = (has_norm || slope != 1.f) ? slope : 1.f;
+    const int HW = g.Hi * g.Wi;
+    int relx[W16_XS], reld[W16_DS];
+#pragma unroll
+    for (int i = 0; i < W16_XS; ++i) {
+      const int v = (lt >> 2) + W16_VPP * i;
+      const int iw = v % 18, t2 = v / 18;
+      relx[i] = ((t2 / 6) * HW + (t2 % 6) * g.Wi + iw) * g.x_ldc + c;
+    }
+#pragma unroll
+    for (int i = 0; i < W16_DS; ++i) {
+      const int v = (lt >> 2) + W16_VPP * i;                  // output voxel: td = v>>6, th = (v>>4)&3, tw = v&15
+      reld[i] = (((v >> 6) * g.Ho + ((v >> 4) & 3)) * g.Wo + (v & 15)) * a.dy_ldc + c;
+    }
+    const bool last_ok = (lt >> 2) + W16_VPP * (W16_XS - 1) < W16_NVOX;
+    const bool dlast_ok = (lt >> 2) + W16_VPP * (W16_DS - 1) < 256;
+    float4 px[1][W16_XS], pd[1][W16_DS];
+    unsigned inbx[1] = {0u}, inbd[1] = {0u};
+    __builtin_amdgcn_s_setprio(1);
+    struct Org { const float* xb; const float* db; bool interior; int id0, ih0, iw0, od0, oh0, ow0, n; };
+    auto origin = [&](int tile) {
+      Org o;
+      o.n = tile / tiles_sp; int rem = tile - o.n * tiles_sp;
+      const int tile_w = rem % g.tiles_w; rem /= g.tiles_w;
+      const int tile_h = rem % g.tiles_h; const int tile_d = rem / g.tiles_h;
+      o.od0 = tile_d * 4; o.oh0 = tile_h * 4; o.ow0 = tile_w * 16;
+      o.id0 = o.od0 - 1; o.ih0 = o.oh0 - 1; o.iw0 = o.ow0 - 1;
+      o.xb = a.x + ((((int64_t)o.n * g.Di + o.id0) * g.Hi + o.ih0) * g.Wi + o.iw0) * g.x_ldc;
+      o.db = a.dy + ((((int64_t)o.n * g.Do + o.od0) * g.Ho + o.oh0) * g.Wo + o.ow0) * a.dy_ldc;
+      o.interior = o.id0 >= 0 && o.id0 + 6 <= g.Di && o.ih0 >= 0 && o.ih0 + 6 <= g.Hi && o.iw0 >= 0 && o.iw0 + 18 <= g.Wi &&
+                   o.od0 + 4 <= g.Do && o.oh0 + 4 <= g.Ho && o.ow0 + 16 <= g.Wo;
+      return o;
+    };
+    auto issue = [&](const Org& o, auto S) {
+      constexpr int SET = decltype(S)::value;
+      unsigned mx = 0, md = 0;
+      if (o.interior) {
+#pragma unroll
+        for (int i = 0; i < W16_XS; ++i) {
+          const bool ok = cval && (i < W16_XS - 1 || last_ok);
+          px[SET][i] = *reinterpret_cast<const float4*>(ok ? o.xb + relx[i] : a.x);
+          mx |= ok ? (1u << i) : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < W16_DS; ++i) {
+          const bool ok = i < W16_DS - 1 || dlast_ok;
+          pd[SET][i] = *reinterpret_cast<const float4*>(ok ? o.db + reld[i] : a.dy);
+          md |= ok ? (1u << i) : 0u;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < W16_XS; ++i) {
+          const int v = (lt >> 2) + W16_VPP * i;
+          const int iw = v % 18, t2 = v / 18;
+          const int gd = o.id0 + t2 / 6, gh = o.ih0 + t2 % 6, gw = o.iw0 + iw;
+          const bool ok = cval && (i < W16_XS - 1 || last_ok) && (unsigned)gd < (unsigned)g.Di && (unsigned)gh < (unsigned)g.Hi && (unsigned)gw < (unsigned)g.Wi;
+          px[SET][i] = *reinterpret_cast<const float4*>(ok ? o.xb + relx[i] : a.x);
+          mx |= ok ? (1u << i) : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < W16_DS; ++i) {
+          const int v = (lt >> 2) + W16_VPP * i;
+          const bool ok = (i < W16_DS - 1 || dlast_ok) && o.od0 + (v >> 6) < g.Do && o.oh0 + ((v >> 4) & 3) < g.Ho && o.ow0 + (v & 15) < g.Wo;
+          pd[SET][i] = *reinterpret_cast<const float4*>(ok ? o.db + reld[i] : a.dy);
+          md |= ok ? (1u << i) : 0u;
+        }
+      }
+      inbx[SET] = mx; inbd[SET] = md;
+    };
+    auto convert = [&](int tc, int buf, auto S) {
+      constexpr int SET = decltype(S)::value;
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_norm && cval) {
+        const int n = tc / tiles_sp;
+        sc = *reinterpret_cast<const float4*>(a.in_scale + (int64_t)n * g.Cin + c);
+        sh = *reinterpret_cast<const float4*>(a.in_shift + (int64_t)n * g.Cin + c);
+      }
+      unsigned short* xh = lds + buf * BUF + (lt >> 2) * 16 + q * 4;
+      unsigned short* xl = xh + XI;
+      unsigned short* dh = lds + buf * BUF + XI * (X3 ? 2 : 1) + (lt >> 2) * 16 + q * 4;
+      unsigned short* dl = dh + DI;
+      const unsigned mx = inbx[SET], md = inbd[SET];
+#pragma unroll
+      for (int i = 0; i < W16_XS; ++i) {
+        if (i == W16_XS - 1 && !last_ok) continue;
+        const float4 val = px[SET][i];
+        const bool was = (mx >> i) & 1u;
+        const float v0 = was ? cwf_act(val.x * sc.x + sh.x, sl) : 0.f, v1 = was ? cwf_act(val.y * sc.y + sh.y, sl) : 0.f;
+        const float v2 = was ? cwf_act(val.z * sc.z + sh.z, sl) : 0.f, v3 = was ? cwf_act(val.w * sc.w + sh.w, sl) : 0.f;
+        uint2 h, l;
+        if (X3) { split2(v0, v1, h.x, l.x); split2(v2, v3, h.y, l.y); } else { h.x = pk_bf16(v0, v1); h.y = pk_bf16(v2, v3); }
+        *reinterpret_cast<uint2*>(xh + i * W16_VPP * 16) = h;
+        if (X3) *reinterpret_cast<uint2*>(xl + i * W16_VPP * 16) = l;
+      }
+#pragma unroll
+      for (int i = 0; i < W16_DS; ++i) {
+        if (i == W16_DS - 1 && !dlast_ok) continue;
+        const float4 val = pd[SET][i];
+        const bool was = (md >> i) & 1u;
+        const float v0 = was ? val.x : 0.f, v1 = was ? val.y : 0.f, v2 = was ? val.z : 0.f, v3 = was ? val.w : 0.f;
+        uint2 h, l;
+        if (X3) { split2(v0, v1, h.x, l.x); split2(v2, v3, h.y, l.y); } else { h.x = pk_bf16(v0, v1); h.y = pk_bf16(v2, v3); }
+        *reinterpret_cast<uint2*>(dh + i * W16_VPP * 16) = h;
+        if (X3) *reinterpret_cast<uint2*>(dl + i * W16_VPP * 16) = l;
+      }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    // one prefetch set: tile it+1 is converted right after the barrier, then tile it+2 is requested (a second register set
+    // spills at this kernel's 168-VGPR budget; measured slower)
+    if (niter > 0) {
+      issue(origin(first), S0{});
+      convert(first, 0, S0{});
+      if (niter > 1) issue(origin(first + 1), S0{});
+    }
+    for (int it = 0; it < niter; ++it) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (it + 1 < niter) {
+        convert(first + it + 1, (it + 1) & 1, S0{});
+        if (it + 2 < niter) issue(origin(first + it + 2), S0{});
+      }
+    }
+  }
+}
+
 // plan: identical decisions to wgrad_mfma.hip (the Python side sizes the workspace through cwf_wgrad_nsplit / _slab_floats)
 extern "C" int cwf_wgrad_nsplit(int op, int N, int Do, int Ho, int Wo, int Cin, int Cout);
 extern "C" int64_t cwf_wgrad_slab_floats(int op, int Cin, int Cout);
 
 extern "C" int cwf_wgrad_mfma_bf16(int op, int x3, const float* x, int x_ldc, const float* in_scale, const float* in_shift, float in_slope,
                                    const float* dy, int dy_ldc, float* partial,
-                                   int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, void* stream) {
+                                   int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int* nsplit_used, void* stream) {
   if (!x || !dy || !partial || N <= 0) return CWF_E_BADARG;
   if ((Cin & 3) || (x_ldc & 3) || ((uintptr_t)x & 15) || ((uintptr_t)partial & 15)) return CWF_E_ALIGN;
   if (in_scale && !in_shift) return CWF_E_BADARG;
@@ -242,6 +477,24 @@ extern "C" int cwf_wgrad_mfma_bf16(int op, int x3, const float* x, int x_ldc, co
     return CWF_E_BADARG;
   a.x = x; a.in_scale = in_scale; a.in_shift = in_shift; a.in_slope = in_slope; a.dy = dy; a.dy_ldc = dy_ldc; a.partial = partial;
   a.ngroups = ngroups; a.tiles_per_split = tps; a.total_tiles = total; a.slab_floats = blocks * 256;
+  if (nsplit_used) *nsplit_used = tapsplit ? wg_splits : wg_splits * 4;
+  if (op == CWF_CONV3_S1 && Cin <= 16 && Cout == 16 && (dy_ldc & 3) == 0 && (((uintptr_t)dy) & 15) == 0 && (int64_t)Do * Ho * Wo >= 32768) {
+    // full-resolution 16-channel layers: persistent producer/consumer kernel, one slab per workgroup (<= 256 <= generic nsplit)
+    int grid = 256; if (grid > total) grid = total;
+    const size_t lds16 = (size_t)2 * (W16_NVOX * 16 + 256 * 16) * sizeof(unsigned short) * (x3 ? 2 : 1);
+    hipStream_t st16 = cwf_stream(stream);
+    static bool at0 = false, at1 = false;
+    if (x3) {
+      if (!at1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at1 = true; }
+      hipLaunchKernelGGL((wgrad16_kernel<true>), dim3(grid), dim3(256 + 64 * W16_LW), lds16, st16, a, total);
+    } else {
+      if (!at0) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at0 = true; }
+      hipLaunchKernelGGL((wgrad16_kernel<false>), dim3(grid), dim3(256 + 64 * W16_LW), lds16, st16, a, total);
+    }
+    CWF_LAUNCH_CHECK();
+    if (nsplit_used) *nsplit_used = grid;
+    return 0;
+  }
   const size_t nvox_in = (size_t)a.g.ID * a.g.IH * a.g.IW;
   const size_t mv = (size_t)a.g.TD * a.g.TH * 16;
   const size_t lds = (nvox_in * 16 + mv * CG * 16) * sizeof(unsigned short) * (x3 ? 2 : 1);

@@ -7,6 +7,8 @@ passed zero-copy as (data_ptr, ldc = stride(3)).
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -159,8 +161,11 @@ class HipBackend:
             self._call("cwf_wgrad_mfma", op, x.data_ptr(), x_ldc, _p(in_scale), _p(in_shift), float(slope),
                        dy.data_ptr(), dy_ldc, part.data_ptr(), n, di, hi, wi, cin, do, ho, wo, cout, self._stream())
         else:
+            used = ctypes.c_int(0)
             self._call("cwf_wgrad_mfma_bf16", op, 1 if mode == "bf16x3" else 0, x.data_ptr(), x_ldc, _p(in_scale), _p(in_shift),
-                       float(slope), dy.data_ptr(), dy_ldc, part.data_ptr(), n, di, hi, wi, cin, do, ho, wo, cout, self._stream())
+                       float(slope), dy.data_ptr(), dy_ldc, part.data_ptr(), n, di, hi, wi, cin, do, ho, wo, cout,
+                       ctypes.addressof(used), self._stream())
+            nsplit = used.value
         dw = torch.empty(w_numel, dtype=_f32, device=x.device)
         db = torch.empty(cout, dtype=_f32, device=x.device) if has_bias_map else None
         self._call("cwf_wgrad_reduce", part.data_ptr(), nsplit, slab, inv_map.data_ptr(), dw.data_ptr(), _p(db), self._stream())

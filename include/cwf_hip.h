@@ -100,7 +100,7 @@ int cwf_wgrad_mfma_bf16(int op, int x3,
                         const float* x, int x_ldc, const float* in_scale, const float* in_shift, float in_slope,
                         const float* dy, int dy_ldc, float* partial,
                         int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
-                        void* stream);
+                        int* nsplit_used /* host out, nullable: slabs actually written (<= cwf_wgrad_nsplit()) */, void* stream);
 int cwf_gather_split_bf16(const struct cwf_gather_desc* table, int nlayers, int64_t max_n, void* stream);
 
 /* dst[i] = map[i] >= 0 ? src[map[i]] : 0 for a table of `nlayers` descriptors resident in device memory
