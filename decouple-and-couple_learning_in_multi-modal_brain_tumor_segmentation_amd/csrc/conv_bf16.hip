@@ -90,7 +90,13 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 15, kq = lane >> 4;
 
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so give every XCD a
+  // CONTIGUOUS range of spatial tiles -- neighbouring tiles share halo rows, which then hit in that XCD's L2.
   int bx = blockIdx.x;
+  {
+    const int nb = gridDim.x;
+    if ((nb & 7) == 0) bx = (bx & 7) * (nb >> 3) + (bx >> 3);
+  }
   const int tile_w = bx % g.tiles_w; bx /= g.tiles_w;
   const int tile_h = bx % g.tiles_h;
   const int tile_d = bx / g.tiles_h;
@@ -126,35 +132,43 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
     __syncthreads();
     // packed weights: block = 64 lanes x (hi 16 B | lo 16 B) = 128 uint4
     const uint4* wchunk = a.wpk + ((int64_t)g.cls_wbase16[cls] + (int64_t)chunk * nsteps * g.ntiles) * 128 + lane * 2;
+    // weights of tap pair s+1 are requested before the MFMAs of pair s (they stream from L2: ~500+ cycles)
+    uint4 bh[NT], bl[NT];
+    auto load_b = [&](int s_) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        bh[j] = make_uint4(0, 0, 0, 0); bl[j] = make_uint4(0, 0, 0, 0);
+        if (nt0 + j < g.ntiles) {
+          const uint4* p = wchunk + ((int64_t)s_ * g.ntiles + nt0 + j) * 128;
+          bh[j] = p[0];
+          if (X3) bl[j] = p[1];
+        }
+      }
+    };
+    load_b(0);
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
       const int t0 = tapofs[2 * s];
       const int t1 = tapofs[(2 * s + 1 < ntaps) ? 2 * s + 1 : 2 * s];     // padded tap: weights are zero, address stays valid
       const int to = (second ? t1 : t0) * 16;
-      uint4 bh[NT], bl[NT];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        bh[j] = make_uint4(0, 0, 0, 0); bl[j] = make_uint4(0, 0, 0, 0);
-        if (nt0 + j < g.ntiles) {
-          const uint4* p = wchunk + ((int64_t)s * g.ntiles + nt0 + j) * 128;
-          bh[j] = p[0];
-          if (X3) bl[j] = p[1];
-        }
-      }
       uint4 ah[MT], al[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         ah[m] = *reinterpret_cast<const uint4*>(xh + abase[m] + to);
         if (X3) al[m] = *reinterpret_cast<const uint4*>(xl + abase[m] + to);
       }
+      uint4 ch[NT], cl[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) { ch[j] = bh[j]; cl[j] = bl[j]; }
+      if (s + 1 < nsteps) load_b(s + 1);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, bh[j]), acc[m][j], 0, 0, 0);
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, ch[j]), acc[m][j], 0, 0, 0);
           if (X3) {
-            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, bl[j]), acc[m][j], 0, 0, 0);
-            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[m]), __builtin_bit_cast(bf16x8, bh[j]), acc[m][j], 0, 0, 0);
+            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, cl[j]), acc[m][j], 0, 0, 0);
+            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[m]), __builtin_bit_cast(bf16x8, ch[j]), acc[m][j], 0, 0, 0);
           }
         }
     }
