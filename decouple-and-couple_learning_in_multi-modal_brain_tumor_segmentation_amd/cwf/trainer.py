@@ -3,14 +3,18 @@
     forward -> softmax_dice + 2x get_separate_loss + 2x get_edge_separate_loss (all weights 1.0, :205-211)
     -> backward -> gradient average over ranks -> Adam(amsgrad) with the poly learning rate (:183,270-273).
 
-Two execution modes:
-  * eager  : every kernel is launched from Python (~2100 launches per step); multi-GPU gradients are all-reduced in buckets
-             from autograd hooks while backward is still running (cwf.parallel.GradSync).
-  * graph  : forward + losses + backward + gradient flattening are captured ONCE into a hipGraph (torch.cuda.graph) and
-             replayed per step: the host cost of a step drops from ~45 ms of launches to one graph launch.  Shapes are static
-             (fixed patch size, per-sample top-k of fixed k), the token selection runs on device, so nothing in the step
-             needs the host.  Multi-GPU: the flat 67 MB gradient buffer is all-reduced after the replay (a few large
-             messages -- the right shape for point-to-point xGMI links), then the single fused Adam kernel runs.
+Execution modes:
+  * eager (default): every kernel is launched from Python (~2000 launches, ~26 ms of host time per step, hidden behind the GPU);
+    the three sub-region pipelines run on parallel HIP streams.
+  * graph: forward + losses + backward + gradient flattening are captured ONCE into a hipGraph (torch.cuda.graph) and replayed
+    per step (host cost ~1 ms).  Shapes are static (fixed patch size, per-sample top-k of fixed k) and the token selection runs
+    on device, so nothing in the step needs the host.  Currently slower end to end than eager (the captured branches overlap less).
+Multi-GPU gradient averaging (the only data-path collective):
+  * default: after backward the flat 67 MB gradient buffer is all-reduced in 4 chunks (a few large messages -- the right shape
+    for point-to-point xGMI links; ~1 ms on an 8-GPU ring, <3 % of the step), then the single fused Adam kernel runs.  Backward's
+    end synchronises every stream, so this is race-free with the multi-stream regions.
+  * overlap_comm=True: bucketed all-reduce launched from autograd hooks while backward is still running (cwf.parallel.GradSync);
+    the regions are then kept on one stream (gradients of one bucket would otherwise be produced on different streams).
 Checkpoints use the reference layout {'epoch', 'state_dict' with 'module.' prefix, 'optim_dict'} (:248-253)."""
 from __future__ import annotations
 
@@ -32,13 +36,17 @@ def total_loss(outputs, target, edge):
 
 class Trainer:
     def __init__(self, model, lr=2e-4, weight_decay=1e-5, amsgrad=True, end_epoch=1000, bucket_mb=16.0, use_graph=False,
-                 graph_warmup=2):
+                 graph_warmup=2, overlap_comm=False):
         self.model = model
         self.init_lr, self.end_epoch = lr, end_epoch
         self.opt = FusedAdam(model.parameters(), lr=lr, weight_decay=weight_decay, amsgrad=amsgrad)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.use_graph = use_graph
-        self.sync = GradSync(model.parameters(), bucket_mb=bucket_mb) if (self.world > 1 and not use_graph) else None
+        self.sync = None
+        if self.world > 1 and overlap_comm and not use_graph:
+            self.sync = GradSync(model.parameters(), bucket_mb=bucket_mb)
+            if hasattr(model, "parallel_regions"):
+                model.parallel_regions = False
         if self.world > 1:
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, 0)
