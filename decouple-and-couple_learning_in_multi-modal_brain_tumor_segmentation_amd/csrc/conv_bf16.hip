@@ -266,12 +266,27 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the role branch below is provably wave-uniform
   const int tiles_sp = g.tiles_d * g.tiles_h * g.tiles_w;
-  // Workgroup b owns the CONTIGUOUS tile range [b*chunk, (b+1)*chunk): consecutive tiles are spatial neighbours, so the
-  // halo rows they share are re-read from this XCD's L2 instead of the fabric (a 256-tile stride put neighbours on other XCDs).
-  const int chunk = (total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int first = blockIdx.x * chunk;
-  if (first >= total_tiles) return;                    // uniform for the whole workgroup
-  const int niter = min(chunk, total_tiles - first);
+  // Tile -> workgroup map (speed only, never correctness).  Workgroups are dealt round-robin over the 8 XCDs, each with its own
+  // L2: XCD x = b & 7 hosts the `per` workgroups s = b >> 3.  Each XCD owns a contiguous range of "strips" of `per`
+  // consecutive tiles (at 128^3: 4 full rows of tiles along H x 8 along W) and its workgroups take one strip per iteration:
+  // neighbours in W and H run on the same XCD in the same or the previous iteration, so their shared halo hits in that XCD's
+  // L2; only the D halo (8 iterations = 10 MB away) falls through to the Infinity Cache.
+  // Measured (2 x 16 x 128^3 bf16x3, PMC FETCH_SIZE x 2 = L2-miss reads; ideal 268 MB):
+  //   tile = b + it*256                      320 MB   0.350 ms
+  //   per-workgroup contiguous chunks        593 MB   0.333 ms
+  //   XCD strips (this map)                  406 MB   0.310 ms   <- fastest
+  //   XCD segment of a whole-plane front     308 MB   0.335 ms   (4 MB address jumps per iteration; used by wgrad16)
+  const int G = (int)gridDim.x, per = G >> 3;                // grid is a multiple of 8, see launcher
+  const int nstrips = (total_tiles + per - 1) / per;
+  const int S = (nstrips + 7) >> 3;                          // strips per XCD
+  const int xcd = blockIdx.x & 7;
+  const int first = xcd * S * per + (blockIdx.x >> 3);       // tile(it) = first + it * per
+  int niter = 0;
+  {
+    const int my_strips = min(S, nstrips - xcd * S);         // may be <= 0 for the last XCDs of a small problem
+    if (my_strips > 0) niter = (first + (my_strips - 1) * per < total_tiles) ? my_strips : my_strips - 1;
+  }
+  if (niter == 0) return;                                    // uniform for the whole workgroup
 
   if (wave < 4) {
     // =============================================================== MFMA waves
@@ -313,7 +328,7 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
 
     unsigned long long d_bar = 0, d_mfma = 0, d_epi = 0;
     for (int it = 0; it < niter; ++it) {
-      const int tile = first + it;
+      const int tile = first + it * per;
       CWF_STAMP(t0);
       // Raw barrier: __syncthreads() would add s_waitcnt vmcnt(0) and make this wave wait for its own output stores.
       asm volatile("s_barrier" ::: "memory");            // buffer it&1 is complete
@@ -506,8 +521,8 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
     // prologue: tile 0 -> set 0 -> LDS buffer 0; then tiles 1 (set 1) and 2 (set 0) in flight
     pre_inb[0] = issue(origin(first), S0{});
     convert(first, 0, S0{});
-    if (niter > 1) pre_inb[1] = issue(origin(first + 1), S1{});
-    if (niter > 2) pre_inb[0] = issue(origin(first + 2), S0{});
+    if (niter > 1) pre_inb[1] = issue(origin(first + per), S1{});
+    if (niter > 2) pre_inb[0] = issue(origin(first + 2 * per), S0{});
     // iteration it: tile it+1 sits in set (it+1)&1 -> LDS buffer (it+1)&1; that set is then refilled with tile it+3
     for (int it = 0; it < niter; ++it) {
       CWF_STAMP(t0);
@@ -516,11 +531,11 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
       CWF_STAMP(t1);
       if (it + 1 < niter) {
         if ((it + 1) & 1) {
-          convert(first + it + 1, 1, S1{});
-          if (it + 3 < niter) pre_inb[1] = issue(origin(first + it + 3), S1{});
+          convert(first + (it + 1) * per, 1, S1{});
+          if (it + 3 < niter) pre_inb[1] = issue(origin(first + (it + 3) * per), S1{});
         } else {
-          convert(first + it + 1, 0, S0{});
-          if (it + 3 < niter) pre_inb[0] = issue(origin(first + it + 3), S0{});
+          convert(first + (it + 1) * per, 0, S0{});
+          if (it + 3 < niter) pre_inb[0] = issue(origin(first + (it + 3) * per), S0{});
         }
       }
       if (DIAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -550,7 +565,7 @@ static int launch_conv16_impl(ConvArgsB a, hipStream_t st) {
     attr_set = true;
   }
   a.diag = DIAG ? g_conv16_diag : nullptr; a.diag_mode = g_conv16_diag_mode;
-  int grid = 256; if (grid > total) grid = total;          // one 8-wave workgroup per CU
+  int grid = 256; while (grid > 8 && grid > total) grid -= 8;   // one 8-wave workgroup per CU; multiple of 8 (XCD map)
   hipLaunchKernelGGL((conv16_kernel<X3, DIAG>), dim3(grid), dim3(512), lds, st, a, total);
   CWF_LAUNCH_CHECK();
   return 0;

@@ -252,9 +252,10 @@ __global__ __launch_bounds__(256 + 64 * W16_LW) void wgrad16_kernel(const WgArgs
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the role branch below is provably wave-uniform
   const int tiles_sp = g.tiles_d * g.tiles_h * g.tiles_w;
-  const int chunk = (total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int first = blockIdx.x * chunk;
-  const int niter = first < total_tiles ? min(chunk, total_tiles - first) : 0;   // empty workgroups still write a zero slab
+  // XCD-aware tile map (see conv16_kernel): iteration `it` covers tiles [it*G, (it+1)*G); XCD x takes segment x of it
+  const int G = (int)gridDim.x, per = G >> 3;
+  const int first = (blockIdx.x & 7) * per + (blockIdx.x >> 3);      // tile(it) = first + it * G
+  const int niter = first < total_tiles ? (total_tiles - first + G - 1) / G : 0;   // empty workgroups still write a zero slab
 
   if (wave < 4) {
     // =============================================================== MFMA waves
@@ -434,13 +435,13 @@ __global__ __launch_bounds__(256 + 64 * W16_LW) void wgrad16_kernel(const WgArgs
     if (niter > 0) {
       issue(origin(first), S0{});
       convert(first, 0, S0{});
-      if (niter > 1) issue(origin(first + 1), S0{});
+      if (niter > 1) issue(origin(first + G), S0{});
     }
     for (int it = 0; it < niter; ++it) {
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (it + 1 < niter) {
-        convert(first + it + 1, (it + 1) & 1, S0{});
-        if (it + 2 < niter) issue(origin(first + it + 2), S0{});
+        convert(first + (it + 1) * G, (it + 1) & 1, S0{});
+        if (it + 2 < niter) issue(origin(first + (it + 2) * G), S0{});
       }
     }
   }
@@ -480,7 +481,7 @@ extern "C" int cwf_wgrad_mfma_bf16(int op, int x3, const float* x, int x_ldc, co
   if (nsplit_used) *nsplit_used = tapsplit ? wg_splits : wg_splits * 4;
   if (op == CWF_CONV3_S1 && Cin <= 16 && Cout == 16 && (dy_ldc & 3) == 0 && (((uintptr_t)dy) & 15) == 0 && (int64_t)Do * Ho * Wo >= 32768) {
     // full-resolution 16-channel layers: persistent producer/consumer kernel, one slab per workgroup (<= 256 <= generic nsplit)
-    int grid = 256; if (grid > total) grid = total;
+    int grid = 256; while (grid > 8 && grid > total) grid -= 8;      // multiple of 8 (XCD-aware tile map)
     const size_t lds16 = (size_t)2 * (W16_NVOX * 16 + 256 * 16) * sizeof(unsigned short) * (x3 ? 2 : 1);
     hipStream_t st16 = cwf_stream(stream);
     static bool at0 = false, at1 = false;
