@@ -305,16 +305,34 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
         for (int i = tid; i < 14 * 64; i += 256) wls[i] = a.wpk[(i >> 6) * 128 + (i & 63) * 2 + 1];
       }
     }
-    int abase[4];
+    // ---- A-fragment addressing.  LDS byte address = buffer parity + per-lane base[m] + tap offset.  The tap pair (2s, 2s+1) of
+    // one K = 32 step is split over lane halves (lanes 32-63 take tap 2s+1), whose offset differs from tap 2s's by one of
+    // three constants (next kw / next kh / next kd) or 0 (last, unpaired tap).  Four classes x four M-tiles of per-lane bases
+    // stay in registers, so the tap offset is the ds_read immediate and the MFMA loop carries no address arithmetic: the
+    // kernel is bound by each SIMD's vector-issue port, shared by its MFMA wave and its loader wave (an MFMA holds it for 8
+    // of its 16 cycles, every other vector instruction for >= 4) -- instructions, not bytes, are what is being saved here.
+    constexpr int D_KW = 32, D_KH = (C16_IW - 2) * 32, D_KD = ((C16_IH - 2) * C16_IW - 2) * 32;
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    typedef const u32x4_t __attribute__((address_space(3)))* lds_u4p;    // 32-bit LDS pointer formed from an integer address
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds4;
+    unsigned ab[4][4];                                   // [class: 0 = +kw, 1 = +kh, 2 = +kd, 3 = same tap][m]
 #pragma unroll
-    for (int m = 0; m < 4; ++m) abase[m] = (((wave * C16_IH + m) * C16_IW + r) * 16 + (kq & 1) * 8) * 2;
+    for (int m = 0; m < 4; ++m) {
+      const unsigned base = lds_base + (((wave * C16_IH + m) * C16_IW + r) * 16 + (kq & 1) * 8) * 2;
+      ab[0][m] = base + (second ? D_KW : 0); ab[1][m] = base + (second ? D_KH : 0);
+      ab[2][m] = base + (second ? D_KD : 0); ab[3][m] = base;
+    }
     const float bv = (a.bias && r < g.Cout) ? a.bias[r] : 0.f;
-    const int ylane = kq * 4 * g.y_ldc + r;
-    const int rlane = kq * 4 * a.r_ldc + r;
+    const f32x4 bias4 = {bv, bv, bv, bv};                // accumulators start from the bias (lane = output channel r)
+    // epilogue addressing: uniform 64-bit row base (SGPRs) + tile-invariant 32-bit lane offsets -> no address VALU per store
+    unsigned yofs[4], rofs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { yofs[i] = (unsigned)((kq * 4 + i) * g.y_ldc + r) * 4u; rofs[i] = (unsigned)((kq * 4 + i) * a.r_ldc + r) * 4u; }   // bytes
     // InstanceNorm statistics of the output: kept in registers over this workgroup's tiles, flushed with one f64 atomic
     // pair per wave and channel when the sample index changes and at the end.
     float s1 = 0.f, s2 = 0.f;
     int stat_n = first / tiles_sp;
+    float osc = 1.f; int osc_n = -1;                     // per-(n, channel) output scale (stem dropout3d), reloaded when n changes
     auto flush_stats = [&](int n_) {
       float u1 = s1, u2 = s2;
       u1 += __shfl_xor(u1, 16, 64); u1 += __shfl_xor(u1, 32, 64);
@@ -325,7 +343,11 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
       }
       s1 = 0.f; s2 = 0.f;
     };
+    // every load issued so far (weights, bias) is complete before the loop: the only VMEM traffic of the loop are the
+    // epilogue's stores, which are never waited for (an s_waitcnt vmcnt(0) at the loop head would expose their latency)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0), expcnt/lgkmcnt untouched
 
+    if (DIAG && (a.diag_mode & 32)) __builtin_amdgcn_s_setprio(1);
     unsigned long long d_bar = 0, d_mfma = 0, d_epi = 0;
     for (int it = 0; it < niter; ++it) {
       const int tile = first + it * per;
@@ -333,24 +355,19 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
       // Raw barrier: __syncthreads() would add s_waitcnt vmcnt(0) and make this wave wait for its own output stores.
       asm volatile("s_barrier" ::: "memory");            // buffer it&1 is complete
       CWF_STAMP(t1);
-      const char* xhb = reinterpret_cast<const char*>(lds + (it & 1) * BUF);
-      const char* xlb = xhb + IMG * 2;
       f32x4 acc[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
       // A fragments are double-buffered in registers: the 8 LDS reads of tap pair s+1 are issued BEFORE the 12 MFMAs of
       // pair s (one MFMA wave per SIMD: nothing else hides the LDS latency).  sched_barrier pins that order.
-      uint4 fa[2][4], fl[2][4], fb[2];
+      u32x4_t fa[2][4], fl[2][4]; uint4 fb[2];
       auto load_step = [&](int s_, int b_) {
         if (X3) fb[b_] = wl[s_ * 64];
-        const int ta = 2 * s_, tb = (2 * s_ + 1 < 27) ? 2 * s_ + 1 : 2 * s_;
+        const int ta = 2 * s_;
         const int oa = (((ta / 9) * C16_IH + (ta / 3) % 3) * C16_IW + ta % 3) * 32;
-        const int ob = (((tb / 9) * C16_IH + (tb / 3) % 3) * C16_IW + tb % 3) * 32;
-        const int to = second ? ob : oa;
+        const int cls = (ta == 26) ? 3 : (ta % 3 != 2) ? 0 : ((ta / 3) % 3 != 2) ? 1 : 2;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          fa[b_][m] = *reinterpret_cast<const uint4*>(xhb + abase[m] + to);
-          if (X3) fl[b_][m] = *reinterpret_cast<const uint4*>(xlb + abase[m] + to);
+          fa[b_][m] = *(lds_u4p)(ab[cls][m] + (unsigned)oa);
+          if (X3) fl[b_][m] = *(lds_u4p)(ab[cls][m] + (unsigned)(oa + IMG * 2));
         }
       };
       load_step(0, 0);
@@ -360,7 +377,7 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][m]), __builtin_bit_cast(bf16x8, bh[s]), acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][m]), __builtin_bit_cast(bf16x8, bh[s]), s == 0 ? bias4 : acc[m], 0, 0, 0);
           if (X3) {
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][m]), __builtin_bit_cast(bf16x8, fb[s & 1]), acc[m], 0, 0, 0);
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fl[s & 1][m]), __builtin_bit_cast(bf16x8, bh[s]), acc[m], 0, 0, 0);
@@ -368,35 +385,73 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      // the other buffer is read next: toggle the parity of the 16 base addresses
+      {
+        const unsigned dlt = (it & 1) ? (unsigned)(-(BUF * 2)) : (unsigned)(BUF * 2);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) ab[c][m] += dlt;
+      }
       CWF_STAMP(t2);
-      // ---- epilogue (uniform tile base + lane offset).  A variant that transposes the accumulators through LDS and stores
-      // one contiguous 1 KiB dwordx4 per M-tile was measured SLOWER (0.54 vs 0.42 ms): the kernel is bound by the L1's
-      // outstanding-miss capacity (TCP_PENDING_STALL ~58 % of CU cycles), and wider bursts make that worse.
+      // ---- epilogue.  (A variant that transposes the accumulators through LDS and stores one contiguous 1 KiB dwordx4 per
+      // M-tile was measured SLOWER.)
       const int n = tile / tiles_sp; int rem = tile - n * tiles_sp;
       const int tile_w = rem % g.tiles_w; rem /= g.tiles_w;
       const int tile_h = rem % g.tiles_h; const int tile_d = rem / g.tiles_h;
       const int od = tile_d * C16_TD + wave, oh0 = tile_h * C16_TH, ow0 = tile_w * 16;
       if (a.stats && n != stat_n) { flush_stats(stat_n); stat_n = n; }     // wave-uniform
-      if (od < g.Do) {                                                      // wave-uniform
+      if (od < g.Do && !(DIAG && (a.diag_mode & 8))) {                      // wave-uniform
         const int64_t vox0 = (((int64_t)n * g.Do + od) * g.Ho + oh0) * g.Wo + ow0;
         float* yb = a.y + vox0 * g.y_ldc;
         const float* rb = a.residual ? a.residual + vox0 * a.r_ldc : nullptr;
-        const float osc = (a.out_scale && r < g.Cout) ? a.out_scale[(int64_t)n * g.Cout + r] : 1.f;
-        const bool full = (oh0 + C16_TH <= g.Ho) && (ow0 + 16 <= g.Wo) && g.Cout == 16;     // wave-uniform
+        const bool hs = a.out_scale != nullptr;
+        if (hs && n != osc_n) {                                               // rare; its wait must not sit in the tile loop
+          osc = r < g.Cout ? a.out_scale[(int64_t)n * g.Cout + r] : 1.f;
+          asm volatile("" :: "v"(osc));                                      // consume here -> the s_waitcnt lands here
+          osc_n = n;
+        }
+        const bool full = (oh0 + C16_TH <= g.Ho) && (ow0 + 16 <= g.Wo) && g.Cout == 16 && !(hs && rb);     // wave-uniform
         if (full) {
-          // branch-free fast path (interior tiles, 16 output channels): 16 stores at uniform-base + lane-offset addresses
+          // branch-free fast path (interior tiles, 16 output channels), specialised on the wave-uniform options so that
+          // an element costs its store + 2 statistics FMAs: 16 stores at SGPR-base + 32-bit lane-offset addresses.
+          // Without a residual the loop issues no loads, so nothing ever waits for the stores (vmcnt is in-order).
+          if (hs) {
 #pragma unroll
-          for (int m = 0; m < 4; ++m) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int eo = m * g.Wo + i;
-              float v = acc[m][i] + bv;
-              if (rb) v += rb[eo * a.r_ldc + rlane];
-              v *= osc;
-              if (!(DIAG && (a.diag_mode & 1))) yb[eo * g.y_ldc + ylane] = v;
-              s1 += v; s2 += v * v;
-            }
+            for (int m = 0; m < 4; ++m) acc[m] *= osc;
           }
+          auto epi = [&](auto HR, auto HT) {
+            constexpr bool HAS_RES = decltype(HR)::value, HAS_STATS = decltype(HT)::value;
+            // The 32-bit lane offsets are made opaque HERE so that their zero-extension stays in this basic block: only then
+            // does instruction selection see "SGPR base + zext(VGPR)" and emit the saddr form (no 64-bit address VALU).
+            unsigned yo[4], ro[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { yo[i] = yofs[i]; asm volatile("" : "+v"(yo[i])); if (HAS_RES) { ro[i] = rofs[i]; asm volatile("" : "+v"(ro[i])); } }
+            float rv[4][4];
+            if (HAS_RES) {
+#pragma unroll
+              for (int m = 0; m < 4; ++m) {
+                const char* rbm = reinterpret_cast<const char*>(rb + (int64_t)m * g.Wo * a.r_ldc);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rv[m][i] = *reinterpret_cast<const float*>(rbm + ro[i]);
+              }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              char* ybm = reinterpret_cast<char*>(yb + (int64_t)m * g.Wo * g.y_ldc);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                float v = acc[m][i];
+                if (HAS_RES) v += rv[m][i];
+                if (!(DIAG && (a.diag_mode & 1))) *reinterpret_cast<float*>(ybm + yo[i]) = v;
+                if (HAS_STATS) { s1 += v; s2 = fmaf(v, v, s2); }
+              }
+            }
+          };
+          using T_ = std::true_type; using F_ = std::false_type;
+          const bool ht = a.stats != nullptr;
+          if (rb) { if (ht) epi(T_{}, T_{}); else epi(T_{}, F_{}); }
+          else    { if (ht) epi(F_{}, T_{}); else epi(F_{}, F_{}); }
         } else {
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
@@ -404,18 +459,18 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
             for (int i = 0; i < 4; ++i) {
               const bool ok = r < g.Cout && oh0 + m < g.Ho && ow0 + kq * 4 + i < g.Wo;
               if (!ok) continue;
-              const int eo = m * g.Wo + i;
-              float v = acc[m][i] + bv;
-              if (rb) v += rb[eo * a.r_ldc + rlane];
+              const int eo = m * g.Wo;
+              float v = acc[m][i];
+              if (rb) v += rb[eo * a.r_ldc + (rofs[i] >> 2)];
               v *= osc;
-              yb[eo * g.y_ldc + ylane] = v;
+              yb[eo * g.y_ldc + (yofs[i] >> 2)] = v;
               s1 += v; s2 += v * v;
             }
           }
         }
       }
       CWF_STAMP(t3);
-      if (DIAG) { d_bar += t1 - t0; d_mfma += t2 - t1; d_epi += t3 - t2; }
+      if (DIAG) { d_bar += t1 - t0; d_mfma += t2 - t1; d_epi += t3 - t2; if (a.diag_mode & 8) { s1 += acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3]; } }
     }
     if (a.stats) flush_stats(stat_n);
     if (DIAG && a.diag && lane == 0) {
@@ -446,7 +501,7 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
     // per-slot branch makes the compiler fall back from counted s_waitcnt vmcnt(N) to vmcnt(0), which serialises the pipeline.
     float4 pre[2][C16_SLOTS];
     unsigned pre_inb[2] = {0u, 0u};
-    __builtin_amdgcn_s_setprio(1);                       // loaders are the critical path: win VALU/VMEM issue arbitration
+    if (!(DIAG && (a.diag_mode & 16))) __builtin_amdgcn_s_setprio(1);   // loaders are the critical path: win VALU/VMEM issue arbitration
     struct TileOrg { const float* base; bool interior; int id0, ih0, iw0, n; };
     auto origin = [&](int tile) {
       TileOrg o;
@@ -466,6 +521,7 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
       if (o.interior) {                                  // wave-uniform; both arms are straight-line
 #pragma unroll
         for (int i = 0; i < C16_SLOTS; ++i) {
+          if (DIAG && (a.diag_mode & 4) && i >= 7) continue;
           const bool ok = lane_ok && (i < C16_SLOTS - 1 || last_slot_ok);
           const float* p = ok ? o.base + rel[i] : a.x;
           pre[SET][i] = *reinterpret_cast<const float4*>(p);
@@ -487,7 +543,11 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
       }
       return inb;
     };
-    // convert register set S (tile tc) into LDS buffer `buf`
+    // convert register set S (tile tc) into LDS buffer `buf`.  Specialised on two wave-uniform facts so that the common case
+    // (interior tile, all 16 channels) carries no per-value selects: PLAIN = no norm/activation prologue (data gradients),
+    // ALLIN = every slot of every lane of this wave was in bounds.  ~22 vector instructions per float4 instead of 34.
+    const unsigned full_mask = last_slot_ok ? ((1u << C16_SLOTS) - 1u) : ((1u << (C16_SLOTS - 1)) - 1u);
+    const bool plain = !has_norm && slope == 1.f;
     auto convert = [&](int tc, int buf, auto S) {
       constexpr int SET = decltype(S)::value;
       float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -496,24 +556,39 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
         sc = *reinterpret_cast<const float4*>(a.in_scale + (int64_t)n * g.Cin + c);
         sh = *reinterpret_cast<const float4*>(a.in_shift + (int64_t)n * g.Cin + c);
       }
-      const float sl = (has_norm || slope != 1.f) ? slope : 1.f;
+      const float sl = slope;
       const unsigned inb = pre_inb[SET];
       unsigned short* dh = lds + buf * BUF + (lt >> 2) * 16 + q * 4;
       unsigned short* dl = dh + IMG;
+      auto body = [&](auto PL, auto AI) {
+        constexpr bool PLAIN = decltype(PL)::value, ALLIN = decltype(AI)::value;
 #pragma unroll
-      for (int i = 0; i < C16_SLOTS; ++i) {
-        if (i == C16_SLOTS - 1 && !last_slot_ok) continue;         // (whole-quad predicate, not per slot: cheap)
-        const float4 val = pre[SET][i];
-        const bool was = (inb >> i) & 1u;
-        // zero padding is applied AFTER the activation: out-of-range voxels stay exactly 0
-        const float v0 = was ? cwf_act(val.x * sc.x + sh.x, sl) : 0.f, v1 = was ? cwf_act(val.y * sc.y + sh.y, sl) : 0.f;
-        const float v2 = was ? cwf_act(val.z * sc.z + sh.z, sl) : 0.f, v3 = was ? cwf_act(val.w * sc.w + sh.w, sl) : 0.f;
-        uint2 h, l;
-        if (X3) { split_bf16(v0, v1, h.x, l.x); split_bf16(v2, v3, h.y, l.y); }
-        else { h.x = pack_bf16(v0, v1); h.y = pack_bf16(v2, v3); }
-        *reinterpret_cast<uint2*>(dh + i * 64 * 16) = h;
-        if (X3) *reinterpret_cast<uint2*>(dl + i * 64 * 16) = l;
-      }
+        for (int i = 0; i < C16_SLOTS; ++i) {
+          if (i == C16_SLOTS - 1 && !last_slot_ok) continue;         // (whole-quad predicate, not per slot: cheap)
+          if (DIAG && (a.diag_mode & 4) && i >= 7) continue;
+          const float4 val = pre[SET][i];
+          float v0 = val.x, v1 = val.y, v2 = val.z, v3 = val.w;
+          if (!PLAIN) {
+            v0 = act01(fmaf(v0, sc.x, sh.x), sl); v1 = act01(fmaf(v1, sc.y, sh.y), sl);
+            v2 = act01(fmaf(v2, sc.z, sh.z), sl); v3 = act01(fmaf(v3, sc.w, sh.w), sl);
+          }
+          uint2 h, l;
+          if (X3) { split_bf16(v0, v1, h.x, l.x); split_bf16(v2, v3, h.y, l.y); }
+          else { h.x = pack_bf16(v0, v1); h.y = pack_bf16(v2, v3); }
+          if (!ALLIN) {
+            // zero padding is applied AFTER the activation: out-of-range voxels are exactly 0 in both images
+            const bool was = (inb >> i) & 1u;
+            h.x = was ? h.x : 0u; h.y = was ? h.y : 0u;
+            if (X3) { l.x = was ? l.x : 0u; l.y = was ? l.y : 0u; }
+          }
+          *reinterpret_cast<uint2*>(dh + i * 64 * 16) = h;
+          if (X3) *reinterpret_cast<uint2*>(dl + i * 64 * 16) = l;
+        }
+      };
+      using T_ = std::true_type; using F_ = std::false_type;
+      const bool allin = __ballot(inb != full_mask) == 0ull;          // wave-uniform
+      if (plain) { if (allin) body(T_{}, T_{}); else body(T_{}, F_{}); }
+      else       { if (allin) body(F_{}, T_{}); else body(F_{}, F_{}); }
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;

@@ -38,19 +38,21 @@ if os.environ.get("CWF_DIAG"):
     K.lib.cwf_debug_conv16_diag.argtypes = [ctypes.c_void_p]; K.lib.cwf_debug_conv16_diag.restype = None
     K.lib.cwf_debug_conv16_diag(diag.data_ptr())
     K.lib.cwf_debug_conv16_mode.argtypes = [ctypes.c_int]; K.lib.cwf_debug_conv16_mode.restype = None
-    for mode in (0, 1, 2, 3):
+    for mode in (0, 64, 13, 13 + 64):
         K.lib.cwf_debug_conv16_mode(mode)
         run(); torch.cuda.synchronize()
         e0.record()
         for _ in range(5): run()
         e1.record(); torch.cuda.synchronize()
-        print("diag build, mode %d (1=no stores, 2=no loads, 3=neither): %.4f ms" % (mode, e0.elapsed_time(e1) / 5))
-    K.lib.cwf_debug_conv16_mode(0)
-    run(); torch.cuda.synchronize()
-    K.lib.cwf_debug_conv16_diag(None)
-    d = diag.cpu().double()
+        print("diag build, mode %d: %.4f ms" % (mode, e0.elapsed_time(e1) / 5))
     tiles = 2 * 8192 / 256
-    m = d[:, :4].mean((0, 1)) / tiles
-    l = d[:, 4:].mean((0, 1)) / tiles
-    print("per tile cycles (s_memtime ticks)  MFMA waves: barrier %.0f  mfma %.0f  epilogue %.0f" % (m[0], m[1], m[2]))
-    print("per tile cycles                  loader waves: barrier %.0f  loadwait %.0f  commit %.0f  fetch %.0f" % (l[0], l[1], l[2], l[3]))
+    for mode in (0, 64, 13, 13 + 64):
+        K.lib.cwf_debug_conv16_mode(mode)
+        diag.zero_(); torch.cuda.synchronize()
+        run(); torch.cuda.synchronize()
+        d = diag.cpu().double()
+        m = d[:, :4].mean((0, 1)) / tiles
+        l = d[:, 4:].mean((0, 1)) / tiles
+        print("mode %2d per tile ticks  MFMA waves: barrier %.0f  mfma %.0f  epilogue %.0f | loader waves: barrier %.0f  commit %.0f" % (mode, m[0], m[1], m[2], l[0], l[2]))
+    K.lib.cwf_debug_conv16_mode(0)
+    K.lib.cwf_debug_conv16_diag(None)
