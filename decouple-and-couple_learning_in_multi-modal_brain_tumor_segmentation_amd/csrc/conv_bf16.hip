@@ -348,6 +348,29 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0), expcnt/lgkmcnt untouched
 
     if (DIAG && (a.diag_mode & 32)) __builtin_amdgcn_s_setprio(1);
+    // Deferred epilogue: the common case (interior tile, no residual, no output scale) is not written out after its MFMA
+    // phase but DURING the next tile's (one element -- a store and two statistics FMAs -- after each of the first 16 MFMA
+    // triples), where those ~50 vector instructions cost issue slots only; done serially they cost ~2k cycles per tile,
+    // because the loader wave of the SIMD is converting at the same time.
+    f32x4 prev[4];                                       // accumulators of the deferred tile
+    float* prev_yb = nullptr;                            // its output base (uniform)
+    int pend = 0;                                        // 0 = nothing deferred, 1 = deferred with statistics, 2 = without
+    auto drain = [&](auto HT) {                          // non-interleaved form (after the last tile)
+      constexpr bool HAS_STATS = decltype(HT)::value;
+      unsigned yo[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { yo[i] = yofs[i]; asm volatile("" : "+v"(yo[i])); }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        char* ybm = reinterpret_cast<char*>(prev_yb + (int64_t)m * g.Wo * g.y_ldc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = prev[m][i];
+          if (!(DIAG && (a.diag_mode & 1))) *reinterpret_cast<float*>(ybm + yo[i]) = v;
+          if (HAS_STATS) { s1 += v; s2 = fmaf(v, v, s2); }
+        }
+      }
+    };
     unsigned long long d_bar = 0, d_mfma = 0, d_epi = 0;
     for (int it = 0; it < niter; ++it) {
       const int tile = first + it * per;
@@ -370,21 +393,39 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
           if (X3) fl[b_][m] = *(lds_u4p)(ab[cls][m] + (unsigned)(oa + IMG * 2));
         }
       };
-      load_step(0, 0);
+      auto phase = [&](auto PEND_) {
+        constexpr int PEND = decltype(PEND_)::value;
+        unsigned yo[4];
+        if (PEND) {
 #pragma unroll
-      for (int s = 0; s < 14; ++s) {
-        if (s + 1 < 14) load_step(s + 1, (s + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][m]), __builtin_bit_cast(bf16x8, bh[s]), s == 0 ? bias4 : acc[m], 0, 0, 0);
-          if (X3) {
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][m]), __builtin_bit_cast(bf16x8, fb[s & 1]), acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fl[s & 1][m]), __builtin_bit_cast(bf16x8, bh[s]), acc[m], 0, 0, 0);
-          }
+          for (int i = 0; i < 4; ++i) { yo[i] = yofs[i]; asm volatile("" : "+v"(yo[i])); }     // see the epilogue: keeps the saddr form
         }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+        load_step(0, 0);
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+          if (s + 1 < 14) load_step(s + 1, (s + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][m]), __builtin_bit_cast(bf16x8, bh[s]), s == 0 ? bias4 : acc[m], 0, 0, 0);
+            if (X3) {
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][m]), __builtin_bit_cast(bf16x8, fb[s & 1]), acc[m], 0, 0, 0);
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fl[s & 1][m]), __builtin_bit_cast(bf16x8, bh[s]), acc[m], 0, 0, 0);
+            }
+            if (PEND != 0 && s < 4) {                    // deferred element: output row s of the previous tile, register m
+              char* ybm = reinterpret_cast<char*>(prev_yb + (int64_t)s * g.Wo * g.y_ldc);
+              const float v = prev[s][m];
+              if (!(DIAG && (a.diag_mode & 1))) *reinterpret_cast<float*>(ybm + yo[m]) = v;
+              if (PEND == 1) { s1 += v; s2 = fmaf(v, v, s2); }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      if (pend == 0) phase(std::integral_constant<int, 0>{});
+      else if (pend == 1) phase(std::integral_constant<int, 1>{});
+      else phase(std::integral_constant<int, 2>{});
+      pend = 0;
       // the other buffer is read next: toggle the parity of the 16 base addresses
       {
         const unsigned dlt = (it & 1) ? (unsigned)(-(BUF * 2)) : (unsigned)(BUF * 2);
@@ -412,7 +453,12 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
           osc_n = n;
         }
         const bool full = (oh0 + C16_TH <= g.Ho) && (ow0 + 16 <= g.Wo) && g.Cout == 16 && !(hs && rb);     // wave-uniform
-        if (full) {
+        if (full && !rb && !hs) {
+          // common case: deferred into the next tile's MFMA phase
+#pragma unroll
+          for (int m = 0; m < 4; ++m) prev[m] = acc[m];
+          prev_yb = yb; pend = a.stats ? 1 : 2;
+        } else if (full) {
           // branch-free fast path (interior tiles, 16 output channels), specialised on the wave-uniform options so that
           // an element costs its store + 2 statistics FMAs: 16 stores at SGPR-base + 32-bit lane-offset addresses.
           // Without a residual the loop issues no loads, so nothing ever waits for the stores (vmcnt is in-order).
@@ -472,6 +518,7 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
       CWF_STAMP(t3);
       if (DIAG) { d_bar += t1 - t0; d_mfma += t2 - t1; d_epi += t3 - t2; if (a.diag_mode & 8) { s1 += acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3]; } }
     }
+    if (pend == 1) drain(std::true_type{}); else if (pend == 2) drain(std::false_type{});
     if (a.stats) flush_stats(stat_n);
     if (DIAG && a.diag && lane == 0) {
       unsigned long long* o = a.diag + ((int64_t)blockIdx.x * 8 + wave) * 4;

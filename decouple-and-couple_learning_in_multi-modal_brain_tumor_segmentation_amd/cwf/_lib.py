@@ -48,7 +48,7 @@ SIGNATURES = {
     "cwf_scatter_rows": [P, P, P, L, L, P, L, P, I, I, I, I, P],
     "cwf_scatter_rows_bwd": [P, P, P, P, L, P, I, P, L, L, P, L, I, I, I, I, P],
     "cwf_upsample_softmax": [P, I, P, I, I, I, I, I, I, P],
-    "cwf_upsample_softmax_bwd": [P, P, P, I, I, I, I, I, I, I, P],
+    "cwf_upsample_softmax_bwd": [P, P, P, I, I, I, I, I, I, I, P, P],
     "cwf_channel_softmax": [P, I, P, L, I, P],
     "cwf_channel_softmax_bwd": [P, P, P, I, L, I, P],
     "cwf_dice_ce_sums": [P, P, U, P, I, L, I, P],

@@ -355,7 +355,8 @@ class HipBackend:
         n, d, h, w = lo_shape
         dprob = dprob.contiguous()
         dl = torch.zeros((n, d, h, w, ldc_out), dtype=_f32, device=prob.device)
-        self._call("cwf_upsample_softmax_bwd", dprob.data_ptr(), prob.data_ptr(), dl.data_ptr(), ldc_out, n, d, h, w, c, scale, self._stream())
+        ws = self.workspace("upsm_bwd", n * d * scale * h * w * c, prob.device)
+        self._call("cwf_upsample_softmax_bwd", dprob.data_ptr(), prob.data_ptr(), dl.data_ptr(), ldc_out, n, d, h, w, c, scale, ws.data_ptr(), self._stream())
         return dl
 
     def channel_softmax(self, logit, c):

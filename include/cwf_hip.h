@@ -192,9 +192,10 @@ int cwf_scatter_rows_bwd(const float* dout, const int32_t* index, const float* s
 /* prob[n][D*s][H*s][W*s][C] = softmax_c( trilinear_up(logit[n][D][H][W][C (ldc)]) ), C in {2,4} */
 int cwf_upsample_softmax(const float* logit, int l_ldc, float* prob, int N, int D, int H, int W, int C, int scale,
                          void* stream);
-/* dlogit (low res) from dprob and prob (high res) */
+/* dlogit (low res) from dprob and prob (high res); workspace: N * D*scale * H * W * C floats (separable two-pass adjoint,
+ * deterministic); writes only channels [0, C) of dlogit */
 int cwf_upsample_softmax_bwd(const float* dprob, const float* prob, float* dlogit, int dl_ldc,
-                             int N, int D, int H, int W, int C, int scale, void* stream);
+                             int N, int D, int H, int W, int C, int scale, float* workspace, void* stream);
 /* prob = softmax over C contiguous channels per voxel; dlogit = p*(dp - sum p*dp) */
 int cwf_channel_softmax(const float* logit, int l_ldc, float* prob, int64_t nvox, int C, void* stream);
 int cwf_channel_softmax_bwd(const float* dprob, const float* prob, float* dlogit, int dl_ldc, int64_t nvox, int C,

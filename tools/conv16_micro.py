@@ -38,7 +38,7 @@ if os.environ.get("CWF_DIAG"):
     K.lib.cwf_debug_conv16_diag.argtypes = [ctypes.c_void_p]; K.lib.cwf_debug_conv16_diag.restype = None
     K.lib.cwf_debug_conv16_diag(diag.data_ptr())
     K.lib.cwf_debug_conv16_mode.argtypes = [ctypes.c_int]; K.lib.cwf_debug_conv16_mode.restype = None
-    for mode in (0, 64, 13, 13 + 64):
+    for mode in (0, 1, 2, 4, 6, 8):
         K.lib.cwf_debug_conv16_mode(mode)
         run(); torch.cuda.synchronize()
         e0.record()
@@ -46,7 +46,7 @@ if os.environ.get("CWF_DIAG"):
         e1.record(); torch.cuda.synchronize()
         print("diag build, mode %d: %.4f ms" % (mode, e0.elapsed_time(e1) / 5))
     tiles = 2 * 8192 / 256
-    for mode in (0, 64, 13, 13 + 64):
+    for mode in (0, 1, 2, 4, 6, 8):
         K.lib.cwf_debug_conv16_mode(mode)
         diag.zero_(); torch.cuda.synchronize()
         run(); torch.cuda.synchronize()
