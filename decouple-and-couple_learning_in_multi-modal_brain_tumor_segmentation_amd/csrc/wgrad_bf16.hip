@@ -224,6 +224,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgsB a) {
 //   * raw s_barrier (lgkmcnt only) hands the buffers over; one slab per workgroup at the end (reduced by cwf_wgrad_reduce).
 // ---------------------------------------------------------------------------------------------------
 #define W16_NVOX 648
+#define W16_XW 20                                       // LDS row pitch of the x image in voxels (18 + 2 pad), see below
+#define W16_DW 20                                       // LDS row pitch of the dy image in voxels (16 + 4 pad)
 #define W16_LW 6                                        // loader waves (MFMA waves: 4) -> 640-thread workgroups
 #define W16_VPP (W16_LW * 16)                           // voxels staged per pass (4 threads per voxel)
 #define W16_XS ((W16_NVOX + W16_VPP - 1) / W16_VPP)     // 7 x staging slots per loader thread
@@ -245,8 +247,11 @@ template <bool X3>
 __global__ __launch_bounds__(256 + 64 * W16_LW) void wgrad16_kernel(const WgArgsB a, int total_tiles) {
   extern __shared__ float4 lds4[];
   const ConvGeom& g = a.g;
-  constexpr int XI = W16_NVOX * 16;                    // bf16 elements of one x image
-  constexpr int DI = 256 * 16;                         // bf16 elements of one dy image
+  // LDS images are voxel-major [row][voxel][16 ch] bf16 with rows PADDED to 20 voxels (640 B): the two M-tile rows that the
+  // lanes of one half-wave read in a transposed fragment then start 128 B apart modulo the 256-B bank period, so the
+  // ds_read_b64_tr_b16 are conflict-free (unpadded: 2-way conflicts, SQ_LDS_BANK_CONFLICT ~ 2k cycles per tile).
+  constexpr int XI = 36 * W16_XW * 16;                 // bf16 elements of one x image  (6 x 6 rows)
+  constexpr int DI = 16 * W16_DW * 16;                 // bf16 elements of one dy image (4 x 4 rows)
   constexpr int BUF = (XI + DI) * (X3 ? 2 : 1);        // per buffer: xh [xl] dh [dl]
   unsigned short* lds = reinterpret_cast<unsigned short*>(lds4);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -267,47 +272,78 @@ __global__ __launch_bounds__(256 + 64 * W16_LW) void wgrad16_kernel(const WgArgs
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     const s16x8 ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
-    // lane-constant part of the transposed-read addresses (bf16 elements): block row bq (+4), column quad bp
-    const int tw0 = (kq & 1) * 8 + bq;
-    int tapo[7];
+    // K = 32 voxels per MFMA = M-tile rows (2ks, 2ks+1) x 16 voxels.  Lane group kq reads row 2ks + (kq & 1), voxels
+    // 8 (kq >> 1) + [0, 8): the two rows met inside one half-wave are 640 B apart (see the padding note above).
+    // Addresses are integers (LDS byte addresses): per-tap bases in registers, everything else in the ds_read immediate, so
+    // the fully unrolled loop has no address arithmetic (same vector-issue argument as conv16_kernel).
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds4;
+    const unsigned lane_x = lds_base + (((kq & 1) * W16_XW + (kq >> 1) * 8 + bq) * 16 + bp * 4) * 2;
+    unsigned xa[7];                                      // x hi image: lane part + tap offset (+ buffer parity)
+    unsigned da = lds_base + XI * 2 * (X3 ? 2 : 1) + (((kq & 1) * W16_DW + (kq >> 1) * 8 + bq) * 16 + bp * 4) * 2;   // dy hi image
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
       const int t = wave + 4 * i;
-      tapo[i] = t < 27 ? (((t / 9) * 6 + (t / 3) % 3) * 18 + t % 3) * 16 : 0;
+      xa[i] = lane_x + (t < 27 ? (((t / 9) * 6 + (t / 3) % 3) * W16_XW + t % 3) * 32 : 0);
     }
-    for (int it = 0; it < niter; ++it) {
-      asm volatile("s_barrier" ::: "memory");            // buffer it&1 is complete
-      const unsigned short* xh = lds + (it & 1) * BUF;
-      const unsigned short* xl = xh + XI;
-      const unsigned short* dh = xh + XI * (X3 ? 2 : 1);
-      const unsigned short* dl = dh + DI;
-#pragma unroll 2
-      for (int ks = 0; ks < 8; ++ks) {                   // 32 voxels per step = M-tiles (2ks, 2ks+1)
-        const int mt = 2 * ks + (kq >> 1);
-        const int vin = (((mt >> 2) * 6 + (mt & 3)) * 18 + tw0) * 16 + bp * 4;
-        const int vout = (mt * 16 + tw0) * 16 + bp * 4;
-        const bf16x8 bhf = tr_frag(dh + vout, dh + vout + 4 * 16);
-        bf16x8 blf;
-        if (X3) blf = tr_frag(dl + vout, dl + vout + 4 * 16);
+    auto trf = [&](unsigned addr) {                      // two transposed reads (block rows +0, +4) -> one 8-element K fragment
+      const s16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)addr);
+      const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(addr + 4 * 32));
+      const s16x8 w = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+      return __builtin_bit_cast(bf16x8, w);
+    };
+    // Two straight-line copies of the whole tile loop (wave 3's last slot is the bias row).  A tile is 8 K-steps x 7 taps =
+    // 56 "tap steps" of 3 MFMAs (48 cycles); the 4 transposed reads of tap step f+2 are issued before the MFMAs of step f
+    // (explicit register double-buffering, pinned with sched_barrier: left alone, the compiler issues each read right
+    // before its MFMA and every MFMA waits out the LDS latency).
+    auto tiles = [&](auto BIAS_) {
+      constexpr bool BIAS = decltype(BIAS_)::value;
+      constexpr int DEPTH = 2;
+      for (int it = 0; it < niter; ++it) {
+        asm volatile("s_barrier" ::: "memory");          // buffer it&1 is complete
+        bf16x8 ah[DEPTH + 1], al[DEPTH + 1], bh[2], bl[2];
+        auto issue = [&](int f) {                        // f = ks * 7 + i, compile-time after unrolling
+          const int ks = f / 7, i = f % 7;
+          if (i == 0) {
+            const unsigned od_ = (2 * ks * W16_DW) * 32;
+            bh[ks & 1] = trf(da + od_);
+            if (X3) bl[ks & 1] = trf(da + od_ + DI * 2);
+          }
+          if (!(BIAS && i == 6)) {
+            const unsigned ox = (((ks >> 1) * 6 + ((2 * ks) & 3)) * W16_XW) * 32;
+            ah[f % (DEPTH + 1)] = trf(xa[i] + ox);
+            if (X3) al[f % (DEPTH + 1)] = trf(xa[i] + ox + XI * 2);
+          }
+        };
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-          const int t = wave + 4 * i;
-          if (t > 27) continue;                          // wave-uniform (waves 0-2 have 7 real taps, wave 3 has 6 + bias)
-          if (t == 27) {
+        for (int f = 0; f < DEPTH; ++f) issue(f);
+#pragma unroll
+        for (int f = 0; f < 56; ++f) {
+          if (f + DEPTH < 56) issue(f + DEPTH);
+          __builtin_amdgcn_sched_barrier(0);
+          const int ks = f / 7, i = f % 7;
+          const bf16x8 bhf = bh[ks & 1];
+          if (BIAS && i == 6) {                          // tap slot 27 = bias row (ones . dy)
             acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bhf, acc[i], 0, 0, 0);
-            if (X3) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, blf, acc[i], 0, 0, 0);
+            if (X3) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bl[ks & 1], acc[i], 0, 0, 0);
           } else {
-            const bf16x8 ahf = tr_frag(xh + vin + tapo[i], xh + vin + tapo[i] + 4 * 16);
+            const bf16x8 ahf = ah[f % (DEPTH + 1)];
             acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahf, bhf, acc[i], 0, 0, 0);
             if (X3) {
-              const bf16x8 alf = tr_frag(xl + vin + tapo[i], xl + vin + tapo[i] + 4 * 16);
-              acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahf, blf, acc[i], 0, 0, 0);
-              acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alf, bhf, acc[i], 0, 0, 0);
+              acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahf, bl[ks & 1], acc[i], 0, 0, 0);
+              acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f % (DEPTH + 1)], bhf, acc[i], 0, 0, 0);
             }
           }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        {                                                // the other buffer is read next
+          const unsigned dlt = (it & 1) ? (unsigned)(-(BUF * 2)) : (unsigned)(BUF * 2);
+#pragma unroll
+          for (int i = 0; i < 7; ++i) xa[i] += dlt;
+          da += dlt;
         }
       }
-    }
+    };
+    if (wave == 3) tiles(std::true_type{}); else tiles(std::false_type{});
     // one slab per workgroup: [tap slot 0..27][lane][4]   (chunk 0, group 0, CG = 1)
     float4* out = reinterpret_cast<float4*>(a.partial + (int64_t)blockIdx.x * a.slab_floats);
 #pragma unroll
@@ -339,6 +375,11 @@ __global__ __launch_bounds__(256 + 64 * W16_LW) void wgrad16_kernel(const WgArgs
     }
     const bool last_ok = (lt >> 2) + W16_VPP * (W16_XS - 1) < W16_NVOX;
     const bool dlast_ok = (lt >> 2) + W16_VPP * (W16_DS - 1) < 256;
+    int xo[W16_XS], dofs[W16_DS];                        // LDS element offsets of this thread's staging slots (padded rows)
+#pragma unroll
+    for (int i = 0; i < W16_XS; ++i) { const int v = (lt >> 2) + W16_VPP * i; xo[i] = ((v / 18) * W16_XW + v % 18) * 16 + q * 4; }
+#pragma unroll
+    for (int i = 0; i < W16_DS; ++i) { const int v = (lt >> 2) + W16_VPP * i; dofs[i] = ((v >> 4) * W16_DW + (v & 15)) * 16 + q * 4; }
     float4 px[1][W16_XS], pd[1][W16_DS];
     unsigned inbx[1] = {0u}, inbd[1] = {0u};
     __builtin_amdgcn_s_setprio(1);
@@ -400,34 +441,55 @@ __global__ __launch_bounds__(256 + 64 * W16_LW) void wgrad16_kernel(const WgArgs
         sc = *reinterpret_cast<const float4*>(a.in_scale + (int64_t)n * g.Cin + c);
         sh = *reinterpret_cast<const float4*>(a.in_shift + (int64_t)n * g.Cin + c);
       }
-      unsigned short* xh = lds + buf * BUF + (lt >> 2) * 16 + q * 4;
+      unsigned short* xh = lds + buf * BUF;
       unsigned short* xl = xh + XI;
-      unsigned short* dh = lds + buf * BUF + XI * (X3 ? 2 : 1) + (lt >> 2) * 16 + q * 4;
+      unsigned short* dh = lds + buf * BUF + XI * (X3 ? 2 : 1);
       unsigned short* dl = dh + DI;
       const unsigned mx = inbx[SET], md = inbd[SET];
+      const unsigned fullx = last_ok ? ((1u << W16_XS) - 1u) : ((1u << (W16_XS - 1)) - 1u);
+      const unsigned fulld = dlast_ok ? ((1u << W16_DS) - 1u) : ((1u << (W16_DS - 1)) - 1u);
+      // specialised on two wave-uniform facts (cf. conv16_kernel): PLAIN = no norm/activation, ALLIN = nothing out of bounds
+      auto body = [&](auto PL, auto AI) {
+        constexpr bool PLAIN = decltype(PL)::value, ALLIN = decltype(AI)::value;
 #pragma unroll
-      for (int i = 0; i < W16_XS; ++i) {
-        if (i == W16_XS - 1 && !last_ok) continue;
-        const float4 val = px[SET][i];
-        const bool was = (mx >> i) & 1u;
-        const float v0 = was ? cwf_act(val.x * sc.x + sh.x, sl) : 0.f, v1 = was ? cwf_act(val.y * sc.y + sh.y, sl) : 0.f;
-        const float v2 = was ? cwf_act(val.z * sc.z + sh.z, sl) : 0.f, v3 = was ? cwf_act(val.w * sc.w + sh.w, sl) : 0.f;
-        uint2 h, l;
-        if (X3) { split2(v0, v1, h.x, l.x); split2(v2, v3, h.y, l.y); } else { h.x = pk_bf16(v0, v1); h.y = pk_bf16(v2, v3); }
-        *reinterpret_cast<uint2*>(xh + i * W16_VPP * 16) = h;
-        if (X3) *reinterpret_cast<uint2*>(xl + i * W16_VPP * 16) = l;
-      }
+        for (int i = 0; i < W16_XS; ++i) {
+          if (i == W16_XS - 1 && !last_ok) continue;
+          const float4 val = px[SET][i];
+          float v0 = val.x, v1 = val.y, v2 = val.z, v3 = val.w;
+          if (!PLAIN) {
+            v0 = fmaxf(fmaf(v0, sc.x, sh.x), fmaf(v0, sc.x, sh.x) * sl); v1 = fmaxf(fmaf(v1, sc.y, sh.y), fmaf(v1, sc.y, sh.y) * sl);
+            v2 = fmaxf(fmaf(v2, sc.z, sh.z), fmaf(v2, sc.z, sh.z) * sl); v3 = fmaxf(fmaf(v3, sc.w, sh.w), fmaf(v3, sc.w, sh.w) * sl);
+          }
+          uint2 h, l;
+          if (X3) { split2(v0, v1, h.x, l.x); split2(v2, v3, h.y, l.y); } else { h.x = pk_bf16(v0, v1); h.y = pk_bf16(v2, v3); }
+          if (!ALLIN) {                                  // zero padding applies after the activation
+            const bool was = (mx >> i) & 1u;
+            h.x = was ? h.x : 0u; h.y = was ? h.y : 0u;
+            if (X3) { l.x = was ? l.x : 0u; l.y = was ? l.y : 0u; }
+          }
+          *reinterpret_cast<uint2*>(xh + xo[i]) = h;
+          if (X3) *reinterpret_cast<uint2*>(xl + xo[i]) = l;
+        }
 #pragma unroll
-      for (int i = 0; i < W16_DS; ++i) {
-        if (i == W16_DS - 1 && !dlast_ok) continue;
-        const float4 val = pd[SET][i];
-        const bool was = (md >> i) & 1u;
-        const float v0 = was ? val.x : 0.f, v1 = was ? val.y : 0.f, v2 = was ? val.z : 0.f, v3 = was ? val.w : 0.f;
-        uint2 h, l;
-        if (X3) { split2(v0, v1, h.x, l.x); split2(v2, v3, h.y, l.y); } else { h.x = pk_bf16(v0, v1); h.y = pk_bf16(v2, v3); }
-        *reinterpret_cast<uint2*>(dh + i * W16_VPP * 16) = h;
-        if (X3) *reinterpret_cast<uint2*>(dl + i * W16_VPP * 16) = l;
-      }
+        for (int i = 0; i < W16_DS; ++i) {
+          if (i == W16_DS - 1 && !dlast_ok) continue;
+          const float4 val = pd[SET][i];
+          uint2 h, l;
+          if (X3) { split2(val.x, val.y, h.x, l.x); split2(val.z, val.w, h.y, l.y); } else { h.x = pk_bf16(val.x, val.y); h.y = pk_bf16(val.z, val.w); }
+          if (!ALLIN) {
+            const bool was = (md >> i) & 1u;
+            h.x = was ? h.x : 0u; h.y = was ? h.y : 0u;
+            if (X3) { l.x = was ? l.x : 0u; l.y = was ? l.y : 0u; }
+          }
+          *reinterpret_cast<uint2*>(dh + dofs[i]) = h;
+          if (X3) *reinterpret_cast<uint2*>(dl + dofs[i]) = l;
+        }
+      };
+      using T_ = std::true_type; using F_ = std::false_type;
+      const bool allin = __ballot(mx != fullx || md != fulld) == 0ull;     // wave-uniform
+      const bool plain = !has_norm && sl == 1.f;
+      if (plain) { if (allin) body(T_{}, T_{}); else body(T_{}, F_{}); }
+      else       { if (allin) body(F_{}, T_{}); else body(F_{}, F_{}); }
     };
     using S0 = std::integral_constant<int, 0>;
     // one prefetch set: tile it+1 is converted right after the barrier, then tile it+2 is requested (a second register set
@@ -482,7 +544,7 @@ extern "C" int cwf_wgrad_mfma_bf16(int op, int x3, const float* x, int x_ldc, co
   if (op == CWF_CONV3_S1 && Cin <= 16 && Cout == 16 && (dy_ldc & 3) == 0 && (((uintptr_t)dy) & 15) == 0 && (int64_t)Do * Ho * Wo >= 32768) {
     // full-resolution 16-channel layers: persistent producer/consumer kernel, one slab per workgroup (<= 256 <= generic nsplit)
     int grid = 256; while (grid > 8 && grid > total) grid -= 8;      // multiple of 8 (XCD-aware tile map)
-    const size_t lds16 = (size_t)2 * (W16_NVOX * 16 + 256 * 16) * sizeof(unsigned short) * (x3 ? 2 : 1);
+    const size_t lds16 = (size_t)2 * (36 * W16_XW * 16 + 16 * W16_DW * 16) * sizeof(unsigned short) * (x3 ? 2 : 1);
     hipStream_t st16 = cwf_stream(stream);
     static bool at0 = false, at1 = false;
     if (x3) {
