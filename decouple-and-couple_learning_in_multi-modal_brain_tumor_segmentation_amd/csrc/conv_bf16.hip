@@ -389,8 +389,8 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
         const int cls = (ta == 26) ? 3 : (ta % 3 != 2) ? 0 : ((ta / 3) % 3 != 2) ? 1 : 2;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          fa[b_][m] = *(lds_u4p)(ab[cls][m] + (unsigned)oa);
-          if (X3) fl[b_][m] = *(lds_u4p)(ab[cls][m] + (unsigned)(oa + IMG * 2));
+          fa[b_][m] = *(lds_u4p)(uintptr_t)(ab[cls][m] + (unsigned)oa);
+          if (X3) fl[b_][m] = *(lds_u4p)(uintptr_t)(ab[cls][m] + (unsigned)(oa + IMG * 2));
         }
       };
       auto phase = [&](auto PEND_) {

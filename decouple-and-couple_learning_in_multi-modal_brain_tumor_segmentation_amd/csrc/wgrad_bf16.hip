@@ -39,6 +39,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned short* p0, const unsign
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// LDS row pitches (in voxels) that make the transposed fragment reads bank-conflict free.  One ds_read_b64_tr_b16 half-wave
+// meets two image rows (lane bit kq & 1) x four block rows (bq) x four 8-byte columns (bp); the two image rows must start
+// 128 B apart modulo the 256-B bank period.  x image: 32 B per voxel -> pitch = 4 (mod 8) for stride-1 geometries (left
+// unpadded for the three stride-2 layers).  dy image, 2*CGW bytes per voxel, 16 voxels per row: CGW = 16 -> pitch 20; CGW = 32:
+// the four block rows already span the bank period at a 64-B stride, so every odd row adds a 32-B skew instead (pitch stays 16:
+// the layer set with 32 output channels keeps two workgroups per CU, which a wider pitch loses); CGW = 64: left as is.
+__host__ __device__ inline int wg_x_pitch(int IW, int is) { if (is != 1) return IW; int p = IW; while ((p & 7) != 4) ++p; return p; }
+__host__ __device__ inline int wg_dy_pitch(int CGW) { return CGW == 16 ? 20 : 16; }
+__host__ __device__ inline int wg_dy_skew(int CGW) { return CGW == 32 ? 16 : 0; }            // bf16 elements added to odd rows
+
 template <int TPW, int NTW, bool TAPSPLIT, bool X3>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgsB a) {
   constexpr int CG = NTW;
@@ -46,11 +56,14 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgsB a) {
   extern __shared__ float4 lds4[];
   const ConvGeom& g = a.g;
   const int nvox_in = g.ID * g.IH * g.IW;
-  const int MV = g.TD * g.TH * 16;
+  const int XW = wg_x_pitch(g.IW, g.is), DP = wg_dy_pitch(CGW);   // padded LDS row pitches (voxels)
+  const int XIMG = g.ID * g.IH * XW * 16;                          // bf16 elements of one x image
+  const int MT = g.TD * g.TH;
   unsigned short* xh = reinterpret_cast<unsigned short*>(lds4);
-  unsigned short* xl = xh + nvox_in * 16;
-  unsigned short* dh = xl + (X3 ? nvox_in * 16 : 0);
-  unsigned short* dl = dh + MV * CGW;
+  unsigned short* xl = xh + XIMG;
+  unsigned short* dh = xl + (X3 ? XIMG : 0);
+  constexpr int DSK = CGW == 32 ? 16 : 0;
+  unsigned short* dl = dh + MT * DP * CGW + (MT / 2 + 1) * DSK;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kq = lane >> 4;
@@ -62,6 +75,13 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgsB a) {
   const int ntaps = g.cls_ntaps[cls];
   const int* tapofs = g.tapofs + (g.ncls > 1 ? cls * 8 : 0);
   const int co0 = grp * CGW;
+  int tapo[TPW];                                         // this wave's tap offsets in the padded image (bf16 elements)
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int t = TAPSPLIT ? wave + 4 * i : i;
+    const int o = t < ntaps ? tapofs[t] : 0;
+    tapo[i] = ((o / g.IW) * XW + o % g.IW) * 16;
+  }
 
   f32x4 acc[TPW][NTW];
 #pragma unroll
@@ -112,17 +132,18 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgsB a) {
           }
         }
         uint2 h; h.x = pack_bf16w(val.x, val.y); h.y = pack_bf16w(val.z, val.w);
-        *reinterpret_cast<uint2*>(xh + v * 16 + q * 4) = h;
+        const int vo = (t2 * XW + iw) * 16 + q * 4;
+        *reinterpret_cast<uint2*>(xh + vo) = h;
         if (X3) {
           uint2 l;
           l.x = pack_bf16w(val.x - bf16_roundw(val.x), val.y - bf16_roundw(val.y));
           l.y = pack_bf16w(val.z - bf16_roundw(val.z), val.w - bf16_roundw(val.w));
-          *reinterpret_cast<uint2*>(xl + v * 16 + q * 4) = l;
+          *reinterpret_cast<uint2*>(xl + vo) = l;
         }
       }
     }
     // ---- dy tile [MV][CGW] as bf16 hi/lo
-    for (int e = tid; e < MV * (CGW / 4); e += 256) {
+    for (int e = tid; e < MT * 16 * (CGW / 4); e += 256) {
       const int vox = e / (CGW / 4), cq = e % (CGW / 4);
       const int tw = vox & 15, mt = vox >> 4;
       const int od = od0 + mt / g.TH, oh = oh0 + mt % g.TH, ow = ow0 + tw;
@@ -144,26 +165,27 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgsB a) {
         }
       }
       uint2 h; h.x = pack_bf16w(val.x, val.y); h.y = pack_bf16w(val.z, val.w);
-      *reinterpret_cast<uint2*>(dh + vox * CGW + cq * 4) = h;
+      const int dofs = (mt * DP + tw) * CGW + ((mt + 1) >> 1) * DSK + cq * 4;   // cumulative skew: rows never overlap
+      *reinterpret_cast<uint2*>(dh + dofs) = h;
       if (X3) {
         uint2 l;
         l.x = pack_bf16w(val.x - bf16_roundw(val.x), val.y - bf16_roundw(val.y));
         l.y = pack_bf16w(val.z - bf16_roundw(val.z), val.w - bf16_roundw(val.w));
-        *reinterpret_cast<uint2*>(dl + vox * CGW + cq * 4) = l;
+        *reinterpret_cast<uint2*>(dl + dofs) = l;
       }
     }
     __syncthreads();
 
-    // ---- K loop: one step = 32 voxels = M-tiles (2ks, 2ks+1); lane group kq -> M-tile 2ks + (kq>>1), voxels 8(kq&1)..+7
+    // ---- K loop: one step = 32 voxels = M-tile rows (2ks, 2ks+1); lane group kq -> row 2ks + (kq&1), voxels 8(kq>>1)..+7
     const int nks = (g.TD * g.TH) >> 1;
 #pragma unroll 1
     for (int ks = 0; ks < nks; ++ks) {
       if (!TAPSPLIT && (ks & 3) != wave) continue;           // 1-tap ops: waves split the voxels (wave-uniform)
-      const int mt = 2 * ks + (kq >> 1);
-      const int tw0 = (kq & 1) * 8 + bq;                     // this lane's block row (first of the two 4-voxel blocks)
-      const int vin = ((((mt / g.TH) * g.is) * g.IH + (mt % g.TH) * g.is) * g.IW + tw0 * g.is) * 16 + bp * 4;
+      const int mt = 2 * ks + (kq & 1);
+      const int tw0 = (kq >> 1) * 8 + bq;                    // this lane's block row (first of the two 4-voxel blocks)
+      const int vin = ((((mt / g.TH) * g.is) * g.IH + (mt % g.TH) * g.is) * XW + tw0 * g.is) * 16 + bp * 4;
       const int vin4 = vin + 4 * g.is * 16;
-      const int vout = (mt * 16 + tw0) * CGW + bp * 4;
+      const int vout = (mt * DP + tw0) * CGW + ((mt + 1) >> 1) * DSK + bp * 4;
       const int vout4 = vout + 4 * CGW;
       bf16x8 bh[NTW], bl[NTW];
 #pragma unroll
@@ -182,7 +204,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgsB a) {
             if (X3) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bl[j], acc[i][j], 0, 0, 0);
           }
         } else {
-          const int to = tapofs[t] * 16;
+          const int to = tapo[i];
           const bf16x8 ah = tr_frag(xh + vin + to, xh + vin4 + to);
           bf16x8 al;
           if (X3) al = tr_frag(xl + vin + to, xl + vin4 + to);
@@ -286,8 +308,8 @@ __global__ __launch_bounds__(256 + 64 * W16_LW) void wgrad16_kernel(const WgArgs
       xa[i] = lane_x + (t < 27 ? (((t / 9) * 6 + (t / 3) % 3) * W16_XW + t % 3) * 32 : 0);
     }
     auto trf = [&](unsigned addr) {                      // two transposed reads (block rows +0, +4) -> one 8-element K fragment
-      const s16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)addr);
-      const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(addr + 4 * 32));
+      const s16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)addr);
+      const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(addr + 4 * 32));
       const s16x8 w = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
       return __builtin_bit_cast(bf16x8, w);
     };
@@ -558,9 +580,9 @@ extern "C" int cwf_wgrad_mfma_bf16(int op, int x3, const float* x, int x_ldc, co
     if (nsplit_used) *nsplit_used = grid;
     return 0;
   }
-  const size_t nvox_in = (size_t)a.g.ID * a.g.IH * a.g.IW;
-  const size_t mv = (size_t)a.g.TD * a.g.TH * 16;
-  const size_t lds = (nvox_in * 16 + mv * CG * 16) * sizeof(unsigned short) * (x3 ? 2 : 1);
+  const size_t ximg = (size_t)a.g.ID * a.g.IH * wg_x_pitch(a.g.IW, a.g.is) * 16;
+  const size_t dimg = (size_t)a.g.TD * a.g.TH * wg_dy_pitch(CG * 16) * CG * 16 + (size_t)(a.g.TD * a.g.TH / 2 + 1) * wg_dy_skew(CG * 16);
+  const size_t lds = (ximg + dimg) * sizeof(unsigned short) * (x3 ? 2 : 1);
   if (lds > 160 * 1024) return CWF_E_TOOLARGE;
   dim3 grid(wg_splits, nchunks * ngroups, ncls);
   hipStream_t st = cwf_stream(stream);
