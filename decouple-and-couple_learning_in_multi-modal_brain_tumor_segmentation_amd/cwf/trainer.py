@@ -83,7 +83,7 @@ class Trainer:
 
     def step(self, x, target, edge, epoch=0):
         """One optimisation step on a rank-local batch.  Returns (loss, [five parts]) as device tensors (no host sync)."""
-        self.opt.param_groups[0]["lr"] = poly_lr(self.init_lr, epoch, self.end_epoch)
+        self.opt.param_groups[0]["lr"] = float(poly_lr(self.init_lr, epoch, self.end_epoch))   # plain float: checkpoints stay weights_only-loadable
         if self.use_graph and self._graph is None and self._eager_steps >= self._graph_warmup:
             torch.cuda.synchronize()
             self._capture(x, target, edge)

@@ -9,6 +9,11 @@ one batch, so they go through the kernels as ONE batch-8 forward.
 
 ``validate_softmax`` (predict_overlap.py:103-171) minus file I/O (nibabel / imageio are not hot-path): argmax over
 classes and the WT / TC / ET Dice of ``utils.tools.softmax_output_dice``.
+
+``flip_tta`` (N4; predict_simple.py:333-349, predict_cls.py:184-203): the reference's 8-flip test-time augmentation -- the
+mean over all subsets of the three spatial axes of ``softmax(model(flip(x))[0]).flip`` (the reference re-applies softmax to
+the model's already-normalised output; kept, ``resoftmax=True``).  The eight flipped copies are independent samples, so
+they run as batches instead of eight sequential B=1 forwards.
 """
 import torch
 
@@ -38,8 +43,29 @@ def tailor_and_concat(x, missing_modal, model, target=None, batched=True):
     return y[..., :155]
 
 
+FLIPS = [(), (2,), (3,), (4,), (2, 3), (2, 4), (3, 4), (2, 3, 4)]          # order of predict_simple.py:333-347
+
+
 @torch.no_grad()
-def validate_softmax(x, target, model, deterministic=True):
+def flip_tta(x, missing_modal, forward, resoftmax=True, batch=8):
+    """x [B,4,D,H,W]; forward(xb, missing_modal) -> probabilities [b,C,D,H,W].  Returns the 8-flip average [B,C,D,H,W]."""
+    nb = x.shape[0]
+    acc = None
+    for g0 in range(0, 8, max(1, batch // max(nb, 1))):
+        group = FLIPS[g0:g0 + max(1, batch // max(nb, 1))]
+        xb = torch.cat([x.flip(dims=f) if f else x for f in group], dim=0)
+        out = forward(xb, missing_modal)
+        for k, f in enumerate(group):
+            o = out[k * nb:(k + 1) * nb]
+            if resoftmax:
+                o = torch.softmax(o, dim=1)
+            o = o.flip(dims=f) if f else o
+            acc = o.clone() if acc is None else acc.add_(o)
+    return acc / 8.0
+
+
+@torch.no_grad()
+def validate_softmax(x, target, model, deterministic=True, use_TTA=False):
     """One subject: stitched probabilities -> label map (argmax; class 3 stands for BraTS label 4) -> [WT, TC, ET] Dice.
     ``deterministic`` zeroes the stem dropout that the reference leaves on in eval mode."""
     model.eval()
@@ -47,7 +73,10 @@ def validate_softmax(x, target, model, deterministic=True):
     if deterministic:
         model.Unet_list.InitConv.dropout = 0.0
     try:
-        prob = tailor_and_concat(x, None, model)
+        if use_TTA:         # each flipped volume goes through the 8-window stitcher (one batch-8 forward per flip)
+            prob = flip_tta(x, None, lambda xb, mm: tailor_and_concat(xb, mm, model), batch=1)
+        else:
+            prob = tailor_and_concat(x, None, model)
     finally:
         model.Unet_list.InitConv.dropout = saved
     seg = prob.argmax(1)

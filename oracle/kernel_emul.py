@@ -296,6 +296,32 @@ class EmulBackend:
         return gscale[0] * g
 
     # ------------------------------------------------------------------ K11 / misc
+    def adam(self, table, ntensors, max_n, lr, beta1, beta2, eps, wd, step, amsgrad, hyper_dev=None):
+        """Pointer-table form of torch.optim.Adam(amsgrad, weight_decay) -- optim.hip / train_no_amp.py:136,239.  Host
+        memory only (CPU tests): rows = [param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, n] raw addresses."""
+        import ctypes
+        import numpy as np
+
+        def view(ptr, n):
+            return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_float * n).from_address(int(ptr))))
+
+        if hyper_dev is not None:
+            step_size, sqrt_bc2 = float(hyper_dev[0]), float(hyper_dev[1])
+        else:
+            step_size, sqrt_bc2 = lr / (1.0 - beta1 ** step), math.sqrt(1.0 - beta2 ** step)
+        for pp, gp, mp, vp, xp, n in table.tolist()[:ntensors]:
+            p_, g_, m_, v_ = view(pp, n), view(gp, n), view(mp, n), view(vp, n)
+            g = g_ + wd * p_
+            m_.mul_(beta1).add_(g, alpha=1.0 - beta1)
+            v_.mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
+            if amsgrad:
+                x_ = view(xp, n)
+                torch.maximum(x_, v_, out=x_)
+                denom = x_.sqrt() / sqrt_bc2 + eps
+            else:
+                denom = v_.sqrt() / sqrt_bc2 + eps
+            p_.addcdiv_(m_, denom, value=-step_size)
+
     def mul(self, a, b):
         return a * b
 

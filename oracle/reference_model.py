@@ -409,6 +409,15 @@ def tailor_and_concat(x, fwd):
     return y[..., :155]
 
 
+def flip_tta(x, fwd):
+    """8-flip test-time augmentation exactly as predict_simple.py:333-349 writes it: eight sequential forwards, softmax
+    re-applied to each (already normalised) output, flipped back, summed in this order, divided by 8.  ``fwd(x)->prob``."""
+    logit = F.softmax(fwd(x), 1)
+    for dims in ((2,), (3,), (4,), (2, 3), (2, 4), (3, 4), (2, 3, 4)):
+        logit = logit + F.softmax(fwd(x.flip(dims=dims)).flip(dims=dims), 1)
+    return logit / 8
+
+
 # --------------------------------------------------------------------------------------
 # parameter inventory (SURVEY Appendix B) and a reference-style train step
 # --------------------------------------------------------------------------------------

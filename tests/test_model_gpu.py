@@ -203,3 +203,28 @@ def test_config4_patch_160x192x160_trains(hip):
         assert np.isfinite(float(loss))
     finally:
         kernels.set_precision("fp32")
+
+
+def test_flip_tta_matches_oracle_64(hip):
+    """N4: 8-flip TTA through the HIP model (flips batched) vs the reference's formula evaluated on the CPU oracle model."""
+    import predict_overlap as po
+    m = _model().eval()
+    x, _, _ = syn.synthetic_batch([4], (64, 64, 64))
+    state = syn.det_state_dict(rm.param_shapes())
+    with torch.no_grad():
+        want = rm.flip_tta(x, lambda v: rm.forward(state, v)[0])
+        got = po.flip_tta(x.to(DEV), None, lambda xb, mm: m(xb, mm)[0]).cpu()
+    assert got.shape == (1, 4, 64, 64, 64)
+    assert float((got - want).abs().max()) < 1e-3
+
+
+def test_training_harness_on_gpu(hip, tmp_path):
+    """N2: the train_no_amp.py counterpart end to end on the GPU (synthetic subjects, 64^3 crops, 3 iterations)."""
+    import train_no_amp as tn
+    rc = tn.main(["--synthetic", "2", "--crop_H", "64", "--crop_W", "64", "--crop_D", "64", "--end_epoch", "2", "--max_iters", "3",
+                  "--log_every", "1", "--num_workers", "0", "--batch_size", "2", "--project_root", str(tmp_path), "--experiment", "g", "--date", "d"])
+    assert rc == 0
+    ck = torch.load(tmp_path / "checkpoint" / "gd" / "model_epoch_last.pth", weights_only=True)
+    assert len(ck["state_dict"]) == 222 and all(k.startswith("module.") for k in ck["state_dict"])
+    from cwf import kernels
+    kernels.set_precision("fp32")
