@@ -38,42 +38,68 @@ __device__ __forceinline__ void split_bf16(float a, float b, unsigned& hi, unsig
 // branch-free (Leaky)ReLU / identity for slope in [0,1]: max(v, slope*v)
 __device__ __forceinline__ float act01(float v, float slope) { return fmaxf(v, v * slope); }
 
-// Stage one 16-channel chunk as bf16 hi (and lo) images [voxel][16].
+// Staging of one 16-channel chunk as bf16 hi (and lo) images [voxel][16].  A workgroup owns one spatial tile for all its
+// channel chunks, so the halo geometry (which global voxel each staging slot of this thread reads, and whether it is in
+// bounds) is computed ONCE (StageSlots) instead of per chunk: the per-chunk loop is load + convert + LDS store only.
+#define CB_MAXS 13                                       // staging slots per thread: ceil(nvox_in / 64) <= 13 (5x5x33 halo)
+struct StageSlots { int goff[CB_MAXS]; unsigned inb; int nslots; };
+
+__device__ __forceinline__ void stage_slots_init(StageSlots& ss, const ConvGeom& g, int id0, int ih0, int iw0, int tid) {
+  const int nvox_in = g.ID * g.IH * g.IW;
+  ss.nslots = (nvox_in + 63) >> 6; ss.inb = 0u;
+#pragma unroll
+  for (int i = 0; i < CB_MAXS; ++i) {
+    const int v = (tid >> 2) + 64 * i;
+    const int iw = v % g.IW; const int t2 = v / g.IW;
+    const int ih = t2 % g.IH; const int idd = t2 / g.IH;
+    const int gd = id0 + idd, gh = ih0 + ih, gw = iw0 + iw;
+    const bool ok = v < nvox_in && gd >= 0 && gd < g.Di && gh >= 0 && gh < g.Hi && gw >= 0 && gw < g.Wi;
+    ss.goff[i] = ok ? ((gd * g.Hi + gh) * g.Wi + gw) * g.x_ldc : 0;
+    ss.inb |= ok ? (1u << i) : 0u;
+  }
+}
+
 template <bool X3>
 __device__ __forceinline__ void stage_tile_bf16(unsigned short* xh, unsigned short* xl, const ConvGeom& g, const float* x,
                                                 const float* in_scale, const float* in_shift, float slope,
-                                                int n, int chunk, int id0, int ih0, int iw0, int tid) {
+                                                int n, int chunk, const StageSlots& ss, int tid) {
   const int q = tid & 3;
   const int c = chunk * 16 + q * 4;
   const bool cval = c < g.Cin;
   const bool has_norm = in_scale != nullptr;
+  const bool plain = !has_norm && slope == 1.f;          // data gradients: no prologue
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
   if (has_norm && cval) {
     sc = *reinterpret_cast<const float4*>(in_scale + (int64_t)n * g.Cin + c);
     sh = *reinterpret_cast<const float4*>(in_shift + (int64_t)n * g.Cin + c);
   }
   const int nvox_in = g.ID * g.IH * g.IW;
-  for (int v = tid >> 2; v < nvox_in; v += 64) {
-    const int iw = v % g.IW; const int t2 = v / g.IW;
-    const int ih = t2 % g.IH; const int idd = t2 / g.IH;
-    const int gd = id0 + idd, gh = ih0 + ih, gw = iw0 + iw;
-    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cval && gd >= 0 && gd < g.Di && gh >= 0 && gh < g.Hi && gw >= 0 && gw < g.Wi) {
-      const int64_t off = ((((int64_t)n * g.Di + gd) * g.Hi + gh) * g.Wi + gw) * g.x_ldc + c;
-      val = *reinterpret_cast<const float4*>(x + off);
-      if (has_norm || slope != 1.f) {
-        val.x = cwf_act(val.x * sc.x + sh.x, slope); val.y = cwf_act(val.y * sc.y + sh.y, slope);
-        val.z = cwf_act(val.z * sc.z + sh.z, slope); val.w = cwf_act(val.w * sc.w + sh.w, slope);
-      }
+  const float* xb = x + (int64_t)n * g.Di * g.Hi * g.Wi * g.x_ldc + c;
+  const unsigned inb = cval ? ss.inb : 0u;
+  unsigned short* dh = xh + (tid >> 2) * 16 + q * 4;
+  unsigned short* dl = xl + (tid >> 2) * 16 + q * 4;
+  float4 val[CB_MAXS];
+#pragma unroll
+  for (int i = 0; i < CB_MAXS; ++i)                      // all loads first (independent), then convert
+    if (i < ss.nslots) val[i] = ((inb >> i) & 1u) ? *reinterpret_cast<const float4*>(xb + ss.goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < CB_MAXS; ++i) {
+    if (i >= ss.nslots) continue;                        // workgroup-uniform
+    if ((tid >> 2) + 64 * i >= nvox_in) continue;
+    float v0 = val[i].x, v1 = val[i].y, v2 = val[i].z, v3 = val[i].w;
+    if (!plain) {
+      v0 = act01(fmaf(v0, sc.x, sh.x), slope); v1 = act01(fmaf(v1, sc.y, sh.y), slope);
+      v2 = act01(fmaf(v2, sc.z, sh.z), slope); v3 = act01(fmaf(v3, sc.w, sh.w), slope);
     }
-    uint2 h; h.x = pack_bf16(val.x, val.y); h.y = pack_bf16(val.z, val.w);
-    *reinterpret_cast<uint2*>(xh + v * 16 + q * 4) = h;
-    if (X3) {
-      uint2 l;
-      l.x = pack_bf16(val.x - bf16_round(val.x), val.y - bf16_round(val.y));
-      l.y = pack_bf16(val.z - bf16_round(val.z), val.w - bf16_round(val.w));
-      *reinterpret_cast<uint2*>(xl + v * 16 + q * 4) = l;
+    uint2 h, l;
+    if (X3) { split_bf16(v0, v1, h.x, l.x); split_bf16(v2, v3, h.y, l.y); }
+    else { h.x = pack_bf16(v0, v1); h.y = pack_bf16(v2, v3); l = make_uint2(0u, 0u); }
+    if (!plain) {                                        // zero padding applies after the activation
+      const bool was = (inb >> i) & 1u;
+      h.x = was ? h.x : 0u; h.y = was ? h.y : 0u; l.x = was ? l.x : 0u; l.y = was ? l.y : 0u;
     }
+    *reinterpret_cast<uint2*>(dh + i * 64 * 16) = h;
+    if (X3) *reinterpret_cast<uint2*>(dl + i * 64 * 16) = l;
   }
 }
 
@@ -86,7 +112,8 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
   unsigned short* xh = reinterpret_cast<unsigned short*>(lds4);
   unsigned short* xl = xh + nvox_in * 16;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: per-wave quantities below stay in SGPRs
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 15, kq = lane >> 4;
 
@@ -126,9 +153,11 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
 
   const int id0 = od0 * g.is + g.lo[0], ih0 = oh0 * g.is + g.lo[1], iw0 = ow0 * g.is + g.lo[2];
 
+  StageSlots ss;
+  stage_slots_init(ss, g, id0, ih0, iw0, tid);
   for (int chunk = 0; chunk < g.nchunks; ++chunk) {
     if (chunk) __syncthreads();
-    stage_tile_bf16<X3>(xh, xl, g, a.x, a.in_scale, a.in_shift, a.in_slope, n, chunk, id0, ih0, iw0, tid);
+    stage_tile_bf16<X3>(xh, xl, g, a.x, a.in_scale, a.in_shift, a.in_slope, n, chunk, ss, tid);
     __syncthreads();
     // packed weights: block = 64 lanes x (hi 16 B | lo 16 B) = 128 uint4
     const uint4* wchunk = a.wpk + ((int64_t)g.cls_wbase16[cls] + (int64_t)chunk * nsteps * g.ntiles) * 128 + lane * 2;
@@ -180,6 +209,61 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
   float s1[NT], s2[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  // fast path (workgroup/wave-uniform test): interior tile of a plain (single-class, unit output stride) geometry with all NT
+  // channel tiles valid -- every store is SGPR row base + tile-invariant 32-bit lane offset, no per-element bounds or
+  // 64-bit address arithmetic (cf. conv16_kernel's epilogue)
+  const bool fast = os == 1 && g.ncls == 1 && od0 + g.TD <= Dc && oh0 + g.TH <= Hc && ow0 + 16 <= Wc && (nt0 + NT) * 16 <= g.Cout &&
+                    !(a.residual && a.out_scale);
+  if (fast) {
+    float bvj[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int co = (nt0 + j) * 16 + r;
+      bvj[j] = a.bias ? a.bias[co] : 0.f;
+      if (a.out_scale) {
+        const float osc = a.out_scale[(int64_t)n * g.Cout + co];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][j] = (acc[m][j] + bvj[j]) * osc;
+        bvj[j] = 0.f;
+      }
+    }
+    auto epi = [&](auto HR, auto HT) {
+      constexpr bool HAS_RES = decltype(HR)::value, HAS_STATS = decltype(HT)::value;
+      unsigned yo[4], ro[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {                      // opaque copies: keep the zero-extension in this block (saddr form)
+        yo[i] = (unsigned)((kq * 4 + i) * g.y_ldc + nt0 * 16 + r) * 4u; asm volatile("" : "+v"(yo[i]));
+        if (HAS_RES) { ro[i] = (unsigned)((kq * 4 + i) * a.r_ldc + nt0 * 16 + r) * 4u; asm volatile("" : "+v"(ro[i])); }
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int mt = wm * MT + m;
+        const int od = od0 + mt / g.TH, oh = oh0 + mt % g.TH;
+        const int64_t vox0 = (((int64_t)n * g.Do + od) * g.Ho + oh) * g.Wo + ow0;
+        char* yb = reinterpret_cast<char*>(a.y + vox0 * g.y_ldc);
+        const char* rb = HAS_RES ? reinterpret_cast<const char*>(a.residual + vox0 * a.r_ldc) : nullptr;
+        float rv[NT][4];
+        if (HAS_RES) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rv[j][i] = *reinterpret_cast<const float*>(rb + ro[i] + j * 64);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float v = acc[m][j][i] + bvj[j];
+            if (HAS_RES) v += rv[j][i];
+            *reinterpret_cast<float*>(yb + yo[i] + j * 64) = v;
+            if (HAS_STATS) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
+          }
+      }
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    if (a.residual) { if (a.stats) epi(T_{}, T_{}); else epi(T_{}, F_{}); }
+    else            { if (a.stats) epi(F_{}, T_{}); else epi(F_{}, F_{}); }
+  } else {
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int co = (nt0 + j) * 16 + r;
@@ -203,6 +287,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
         s1[j] += v; s2[j] += v * v;
       }
     }
+  }
   }
   if (a.stats) {
     __syncthreads();
