@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgsB a) {
   constexpr int DSK = CGW == 32 ? 16 : 0;
   unsigned short* dl = dh + MT * DP * CGW + (MT / 2 + 1) * DSK;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-dependent choices stay uniform
   const int kq = lane >> 4;
   const int bq = (lane & 15) >> 2, bp = lane & 3;        // transposed-read block row / column quad supplied by this lane
   const int split = blockIdx.x;
@@ -99,6 +100,24 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgsB a) {
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   const s16x8 ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
+
+  // set-up of the stride-1 fast path (see the K loop)
+  const bool geo_s1 = TAPSPLIT && g.is == 1 && g.TD == 4 && g.TH == 4 && g.ID == 6 && g.IH == 6 && g.IW == 18 && ntaps == 27;
+  const s16x8 zeros_s = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bf16x8 zeros8 = __builtin_bit_cast(bf16x8, zeros_s);
+  const bool s1_bias_wave = wave == 3;
+  unsigned s1_xa[TPW], s1_da = 0;
+  {
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds4;
+    const unsigned lane_x = lds_base + (((kq & 1) * 20 + (kq >> 1) * 8 + bq) * 16 + bp * 4) * 2;
+    constexpr int DPc = CGW == 16 ? 20 : 16, DSKc = CGW == 32 ? 16 : 0;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      const int t = wave + 4 * i;
+      s1_xa[i] = lane_x + (t < 27 ? (((t / 9) * 6 + (t / 3) % 3) * 20 + t % 3) * 32 : 0);
+    }
+    s1_da = lds_base + 36 * 20 * 16 * 2 * (X3 ? 2 : 1) + (((kq & 1) * DPc + (kq >> 1) * 8 + bq) * CGW + (kq & 1) * DSKc + bp * 4) * 2;
+  }
 
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int n = tile / tiles_sp; int rem = tile % tiles_sp;
@@ -176,6 +195,59 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgsB a) {
     }
     __syncthreads();
 
+    if (TAPSPLIT && geo_s1) {
+      // ---- 3x3x3 stride-1 geometry (6 x 6 x 18 halo, 16 M-tile rows): everything but the per-lane bases is a compile-time
+      // immediate, the bias row is folded in by operand selection (ones / zeros), and the transposed reads of tap step f+2
+      // are issued before the MFMAs of step f (cf. wgrad16_kernel).  56 tap steps x NTW x 3 MFMAs per tile and wave.
+      constexpr int DEPTH = 2;
+      constexpr unsigned XLO = 36 * 20 * 16 * 2;                                     // x lo image (bytes past the hi image)
+      constexpr unsigned DLO = (16 * (CGW == 16 ? 20 : 16) * CGW + (16 / 2 + 1) * (CGW == 32 ? 16 : 0)) * 2;   // dy lo image
+      constexpr int DPc = CGW == 16 ? 20 : 16, DSKc = CGW == 32 ? 16 : 0;
+      bf16x8 ah[DEPTH + 1], al[DEPTH + 1], bh[2][NTW], bl[2][NTW];
+      auto trf = [&](unsigned addr, unsigned second) {       // two transposed reads -> one 8-element K fragment
+        const s16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)addr);
+        const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(addr + second));
+        const s16x8 w = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+        return __builtin_bit_cast(bf16x8, w);
+      };
+      auto issue = [&](int f) {                              // f = ks * 7 + i, compile-time after unrolling
+        const int ks = f / 7, i = f % 7;
+        if (i == 0) {
+          const unsigned od_ = (2 * ks * DPc * CGW + ks * DSKc) * 2;
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) {
+            bh[ks & 1][j] = trf(s1_da + od_ + j * 32, 4 * CGW * 2);
+            if (X3) bl[ks & 1][j] = trf(s1_da + od_ + j * 32 + DLO, 4 * CGW * 2);
+          }
+        }
+        const unsigned ox = (((ks >> 1) * 6 + ((2 * ks) & 3)) * 20) * 32;
+        ah[f % (DEPTH + 1)] = trf(s1_xa[i] + ox, 4 * 32);
+        if (X3) al[f % (DEPTH + 1)] = trf(s1_xa[i] + ox + XLO, 4 * 32);
+      };
+#pragma unroll
+      for (int f = 0; f < DEPTH; ++f) issue(f);
+#pragma unroll
+      for (int f = 0; f < 56; ++f) {
+        if (f + DEPTH < 56) issue(f + DEPTH);
+        __builtin_amdgcn_sched_barrier(0);
+        const int ks = f / 7, i = f % 7;
+        bf16x8 ahf = ah[f % (DEPTH + 1)], alf = al[f % (DEPTH + 1)];
+        if (i == 6) {                                        // wave 3: tap slot 27 = bias row (ones . dy); wave-uniform select
+          ahf = s1_bias_wave ? ones : ahf;
+          if (X3) alf = s1_bias_wave ? zeros8 : alf;
+        }
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahf, bh[ks & 1][j], acc[i][j], 0, 0, 0);
+          if (X3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahf, bl[ks & 1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alf, bh[ks & 1][j], acc[i][j], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      continue;
+    }
     // ---- K loop: one step = 32 voxels = M-tile rows (2ks, 2ks+1); lane group kq -> row 2ks + (kq&1), voxels 8(kq>>1)..+7
     const int nks = (g.TD * g.TH) >> 1;
 #pragma unroll 1
