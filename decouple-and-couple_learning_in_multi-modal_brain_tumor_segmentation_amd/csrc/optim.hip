@@ -75,6 +75,31 @@ __global__ void copy_strided_kernel(const float* __restrict__ x, int x_ldc, floa
   *reinterpret_cast<float4*>(y + gv * y_ldc + cq * 4) = *reinterpret_cast<const float4*>(x + gv * x_ldc + cq * 4);
 }
 
+// K12 -- pre-scaled dropout keep-mask in ONE launch (F.dropout / nn.Dropout sites of the token path, SelfAttention.py:96-100,
+// ResidualNorm.py:25-31,40-45): mask[i] = keep_i / (1 - p), keep_i ~ Bernoulli(1 - p) from a counter-based generator
+// (splitmix64 of seed and element counter -- reproducible for a given torch seed and call order, no generator state on the
+// device).  p2 > 0 multiplies a second, independent mask in (two dropouts acting in sequence on one tensor).
+__device__ __forceinline__ float cwf_u01(uint64_t seed, uint64_t ctr) {
+  uint64_t z = (seed ^ 0x9E3779B97F4A7C15ull) + ctr * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+__global__ void dropout_mask_kernel(float* __restrict__ m, int64_t n, float p, float p2, uint64_t seed, uint64_t offset) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = cwf_u01(seed, offset + (uint64_t)i) >= p ? 1.0f / (1.0f - p) : 0.f;
+  if (p2 > 0.f) v *= cwf_u01(seed, offset + (uint64_t)n + (uint64_t)i) >= p2 ? 1.0f / (1.0f - p2) : 0.f;
+  m[i] = v;
+}
+extern "C" int cwf_dropout_mask(float* mask, int64_t n, float p, float p2, uint64_t seed, uint64_t offset, void* stream) {
+  if (!mask || n <= 0 || p < 0.f || p >= 1.f || p2 < 0.f || p2 >= 1.f) return CWF_E_BADARG;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, cwf_stream(stream), mask, n, p, p2, seed, offset);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int cwf_mul(const float* a, const float* b, float* y, int64_t n, void* stream) {
   if (!a || !b || !y || n <= 0) return CWF_E_BADARG;
   hipLaunchKernelGGL(mul_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, cwf_stream(stream), a, b, y, n);

@@ -55,6 +55,7 @@ SIGNATURES = {
     "cwf_dice_ce_finalize": [P, P, P, I, L, I, P],
     "cwf_dice_ce_bwd": [P, P, U, P, P, P, I, L, I, P],
     "cwf_adam_amsgrad": [P, I, L, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P, P],
+    "cwf_dropout_mask": [P, L, F, F, C.c_uint64, C.c_uint64, P],
     "cwf_mul": [P, P, P, L, P],
     "cwf_add": [P, P, P, L, P],
     "cwf_channel_scale": [P, I, P, P, I, I, L, I, P],

@@ -423,9 +423,9 @@ def add(a, b):
     return _AddFn.apply(a, b)
 
 
-def dropout_mask(shape, p, device):
-    """Pre-scaled keep mask (torch's device RNG supplies the bits; the multiply is a HIP kernel)."""
-    return (torch.rand(shape, device=device) >= p).to(torch.float32) * (1.0 / (1.0 - p))
+def dropout_mask(shape, p, device, p2=0.0):
+    """Pre-scaled keep mask, one launch (K12); p2 > 0 folds a second independent dropout of the same tensor in."""
+    return backend().dropout_mask(tuple(shape), float(p), device, float(p2))
 
 
 def dropout(x, p, training):

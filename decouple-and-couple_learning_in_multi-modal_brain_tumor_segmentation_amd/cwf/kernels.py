@@ -9,6 +9,8 @@ from __future__ import annotations
 
 import ctypes
 
+import threading
+
 import torch
 
 from . import _lib
@@ -66,6 +68,8 @@ class HipBackend:
         self._ws = {}
         self._arena = {}
         self._arena_off = {}
+        self._rng_counter = 0
+        self._rng_lock = threading.Lock()      # the autograd engine may call in from its own thread
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -395,6 +399,24 @@ class HipBackend:
     def adam(self, table, ntensors, max_n, lr, beta1, beta2, eps, wd, step, amsgrad, hyper_dev=None):
         self._call("cwf_adam_amsgrad", table.data_ptr(), ntensors, max_n, lr, beta1, beta2, eps, wd, step, int(amsgrad),
                    _p(hyper_dev), self._stream())
+
+    def dropout_mask(self, shape, p, device, p2=0.0):
+        """Pre-scaled keep mask(s) in one launch.  Counter-based: (torch seed, running element counter) -> reproducible for
+        a given seed and call order.  Under stream capture the counter could not advance between replays, so that case
+        uses torch's capture-aware generator instead."""
+        if torch.cuda.is_current_stream_capturing():
+            m = (torch.rand(shape, device=device) >= p).to(_f32) * (1.0 / (1.0 - p))
+            if p2 > 0.0:
+                m = m * ((torch.rand(shape, device=device) >= p2).to(_f32) * (1.0 / (1.0 - p2)))
+            return m
+        m = torch.empty(shape, dtype=_f32, device=device)
+        n = m.numel()
+        seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+        with self._rng_lock:
+            off = self._rng_counter
+            self._rng_counter = (off + 2 * n) & 0xFFFFFFFFFFFFFFFF
+        self._call("cwf_dropout_mask", m.data_ptr(), n, float(p), float(p2), seed, off, self._stream())
+        return m
 
     def mul(self, a, b):
         a, b = a.contiguous(), b.contiguous()

@@ -80,7 +80,7 @@ def _cross_attention(block: Residual, x, x2):
     keep = None
     if block.training and (pre.dropout_rate > 0 or attn.dropout_rate > 0):
         # drop_output (inside the attention) and PreNormDrop.dropout act in sequence on the same tensor
-        keep = CF.dropout_mask(x.shape, attn.dropout_rate, x.device) * CF.dropout_mask(x.shape, pre.dropout_rate, x.device)
+        keep = CF.dropout_mask(x.shape, attn.dropout_rate, x.device, p2=pre.dropout_rate)
     return attn(a, b, residual=x, out_keep=keep)
 
 

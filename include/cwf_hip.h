@@ -231,6 +231,9 @@ int cwf_adam_amsgrad(const struct cwf_adam_desc* table, int ntensors, int64_t ma
  * K12 / misc elementwise
  * ---------------------------------------------------------------------------------------------- */
 /* y[i] = a[i]*b[i]  (dropout masks) ; y = a + b ; y[n][v][c] = x[n][v][c]*s[n][c] (dropout3d) ; fill */
+/* K12: mask[i] = Bernoulli(1-p)/(1-p) [* Bernoulli(1-p2)/(1-p2)], counter-based (seed, offset + i): replaces the
+ * rand / compare / cast / scale sequence behind F.dropout (SelfAttention.py:96-100, ResidualNorm.py:25-31,40-45) */
+int cwf_dropout_mask(float* mask, int64_t n, float p, float p2, uint64_t seed, uint64_t offset, void* stream);
 int cwf_mul(const float* a, const float* b, float* y, int64_t n, void* stream);
 int cwf_add(const float* a, const float* b, float* y, int64_t n, void* stream);
 int cwf_channel_scale(const float* x, int x_ldc, const float* s, float* y, int y_ldc, int N, int64_t V, int C, void* stream);

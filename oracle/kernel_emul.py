@@ -322,6 +322,12 @@ class EmulBackend:
                 denom = v_.sqrt() / sqrt_bc2 + eps
             p_.addcdiv_(m_, denom, value=-step_size)
 
+    def dropout_mask(self, shape, p, device, p2=0.0):
+        m = (torch.rand(shape, device=device) >= p).float() * (1.0 / (1.0 - p))
+        if p2 > 0.0:
+            m = m * ((torch.rand(shape, device=device) >= p2).float() * (1.0 / (1.0 - p2)))
+        return m
+
     def mul(self, a, b):
         return a * b
 

@@ -334,3 +334,21 @@ def test_fused_adam_against_torch_fixture(hip):
     close(st["max_exp_avg_sq"], torch.from_numpy(g["max_exp_avg_sq"]), rtol=1e-6)
     sd = opt.state_dict()     # torch.optim.Adam-compatible layout (train_no_amp.py:252 'optim_dict')
     assert set(sd["state"][0].keys()) >= {"step", "exp_avg", "exp_avg_sq", "max_exp_avg_sq"}
+
+
+def test_dropout_mask_kernel(hip):
+    """K12 fused keep-mask: values in {0, 1/(1-p)}, drop rate ~ p, independent second mask, reproducible per (seed, counter)."""
+    torch.manual_seed(123)
+    hip._rng_counter = 0
+    m = hip.dropout_mask((4, 8, 129, 129), 0.1, DEV).cpu()
+    vals = torch.unique(m)
+    assert len(vals) == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1 / 0.9) < 1e-6
+    assert abs(float((m == 0).float().mean()) - 0.1) < 5e-3
+    m2 = hip.dropout_mask((4, 8, 129, 129), 0.1, DEV, p2=0.2).cpu()
+    assert abs(float((m2 == 0).float().mean()) - (1 - 0.9 * 0.8)) < 5e-3 and abs(float(m2.mean()) - 1.0) < 1e-2
+    assert not torch.equal(m != 0, m2 != 0)
+    hip._rng_counter = 0
+    assert torch.equal(hip.dropout_mask((4, 8, 129, 129), 0.1, DEV).cpu(), m)
+    # neighbouring elements are uncorrelated (lag-1 autocorrelation of the keep bits)
+    k = (m.reshape(-1) != 0).float(); k = k - k.mean()
+    assert abs(float((k[1:] * k[:-1]).mean() / (k * k).mean())) < 1e-2
