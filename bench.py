@@ -145,9 +145,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # Rehearsal switch (not used by the driver): CWF_BENCH_REHEARSE=1 runs the N > 1 code path with all ranks on cuda:0 over
+    # gloo, for a one-GPU box -- the numbers mean nothing, the control flow (broadcast, all-reduce, barriers, MAX) is what runs.
+    rehearse = os.environ.get("CWF_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -199,9 +207,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA operands hi.hi+hi.lo+lo.hi, f32 accumulate, f32 storage)",
                       "bf16": "bf16 (MFMA operands; f32 accumulate, f32 storage)"}[args.precision], "data": "synthetic",
-            "config": {"workload": "configs[1]: 1xMI355X, batch %d per GPU, 4-modality %d^3 synthetic BraTS patches; "
-                                   "fwd + softmax_dice + 4 sub-region/edge losses + bwd + Adam(amsgrad); random-init weights, dropout on"
-                                   % (args.batch, args.size),
+            "config": {"workload": "%s: %dxMI355X, batch %d per GPU, 4-modality %d^3 synthetic BraTS patches; "
+                                   "fwd + softmax_dice + 4 sub-region/edge losses + bwd + Adam(amsgrad)%s; random-init weights, dropout on"
+                                   % ("configs[1]" if world == 1 else ("configs[2]" if world == 8 else "configs[1] per GPU, data-parallel"),
+                                      world, args.batch, args.size, "" if world == 1 else " + gradient all-reduce (RCCL)"),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "precision": args.precision, "graph": bool(args.graph)},
             "final_loss": round(final_loss, 5), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 2),
             "end_to_end": {"tflops": round(value * FLOP_PER_TRAIN_VOLUME * (args.size / 128.0) ** 3 / 1e12, 2),
