@@ -155,51 +155,61 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
 
   StageSlots ss;
   stage_slots_init(ss, g, id0, ih0, iw0, tid);
+  // Packed weights stream from L2 (~1-2k cycles of latency) while one tap-pair step is only MT*NT*3 MFMAs (96 cycles for the
+  // deep 1x2 configuration): a ring of PD steps of B fragments is kept in flight, and the first PD loads of a chunk are
+  // issued BEFORE the chunk's activation staging so that their latency hides under it.
+  constexpr int PD = MT == 1 ? (NT <= 2 ? 4 : 2) : 1;   // large-MT configurations: one step ahead (deeper rings cost them an occupancy step)
   for (int chunk = 0; chunk < g.nchunks; ++chunk) {
-    if (chunk) __syncthreads();
-    stage_tile_bf16<X3>(xh, xl, g, a.x, a.in_scale, a.in_shift, a.in_slope, n, chunk, ss, tid);
-    __syncthreads();
     // packed weights: block = 64 lanes x (hi 16 B | lo 16 B) = 128 uint4
     const uint4* wchunk = a.wpk + ((int64_t)g.cls_wbase16[cls] + (int64_t)chunk * nsteps * g.ntiles) * 128 + lane * 2;
-    // weights of tap pair s+1 are requested before the MFMAs of pair s (they stream from L2: ~500+ cycles)
-    uint4 bh[NT], bl[NT];
-    auto load_b = [&](int s_) {
+    uint4 bh[PD][NT], bl[PD][NT];
+    auto load_b = [&](int s_, int slot) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        bh[j] = make_uint4(0, 0, 0, 0); bl[j] = make_uint4(0, 0, 0, 0);
-        if (nt0 + j < g.ntiles) {
+        bh[slot][j] = make_uint4(0, 0, 0, 0); bl[slot][j] = make_uint4(0, 0, 0, 0);
+        if (nt0 + j < g.ntiles && s_ < nsteps) {
           const uint4* p = wchunk + ((int64_t)s_ * g.ntiles + nt0 + j) * 128;
-          bh[j] = p[0];
-          if (X3) bl[j] = p[1];
+          bh[slot][j] = p[0];
+          if (X3) bl[slot][j] = p[1];
         }
       }
     };
-    load_b(0);
+#pragma unroll
+    for (int d = 0; d < PD; ++d) load_b(d, d);
+    if (chunk) __syncthreads();
+    stage_tile_bf16<X3>(xh, xl, g, a.x, a.in_scale, a.in_shift, a.in_slope, n, chunk, ss, tid);
+    __syncthreads();
 #pragma unroll 1
-    for (int s = 0; s < nsteps; ++s) {
-      const int t0 = tapofs[2 * s];
-      const int t1 = tapofs[(2 * s + 1 < ntaps) ? 2 * s + 1 : 2 * s];     // padded tap: weights are zero, address stays valid
-      const int to = (second ? t1 : t0) * 16;
-      uint4 ah[MT], al[MT];
+    for (int s0 = 0; s0 < nsteps; s0 += PD) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        ah[m] = *reinterpret_cast<const uint4*>(xh + abase[m] + to);
-        if (X3) al[m] = *reinterpret_cast<const uint4*>(xl + abase[m] + to);
-      }
-      uint4 ch[NT], cl[NT];
+      for (int d = 0; d < PD; ++d) {
+        const int s = s0 + d;
+        if (s < nsteps) {                                  // workgroup-uniform
+          const int t0 = tapofs[2 * s];
+          const int t1 = tapofs[(2 * s + 1 < ntaps) ? 2 * s + 1 : 2 * s];     // padded tap: weights are zero, address stays valid
+          const int to = (second ? t1 : t0) * 16;
+          uint4 ah[MT], al[MT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) { ch[j] = bh[j]; cl[j] = bl[j]; }
-      if (s + 1 < nsteps) load_b(s + 1);
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, ch[j]), acc[m][j], 0, 0, 0);
-          if (X3) {
-            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, cl[j]), acc[m][j], 0, 0, 0);
-            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[m]), __builtin_bit_cast(bf16x8, ch[j]), acc[m][j], 0, 0, 0);
+          for (int m = 0; m < MT; ++m) {
+            ah[m] = *reinterpret_cast<const uint4*>(xh + abase[m] + to);
+            if (X3) al[m] = *reinterpret_cast<const uint4*>(xl + abase[m] + to);
           }
+          uint4 ch[NT], cl[NT];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) { ch[j] = bh[d][j]; cl[j] = bl[d][j]; }
+          load_b(s + PD, d);                               // refill this ring slot (no-op past the last step)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, ch[j]), acc[m][j], 0, 0, 0);
+              if (X3) {
+                acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, cl[j]), acc[m][j], 0, 0, 0);
+                acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[m]), __builtin_bit_cast(bf16x8, ch[j]), acc[m][j], 0, 0, 0);
+              }
+            }
         }
+      }
     }
   }
 
