@@ -58,6 +58,10 @@ def precision() -> str:
     return _PRECISION
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_current_device = torch._C._cuda_getDevice
+
+
 class HipBackend:
     name = "hip"
 
@@ -74,7 +78,9 @@ class HipBackend:
     # ------------------------------------------------------------------ helpers
     @staticmethod
     def _stream():
-        return torch.cuda.current_stream().cuda_stream
+        # raw hipStream_t of the current torch stream.  torch.cuda.current_stream() costs ~8 us of Python per call (device
+        # index resolution, os.environ look-ups) -- with ~470 launches per forward that was 10 % of the host time.
+        return _raw_stream(_current_device())
 
     def _call(self, name, *args):
         rc = getattr(self.lib, name)(*args)
@@ -83,7 +89,7 @@ class HipBackend:
 
     def workspace(self, key, nfloats, device):
         """Grow-only scratch buffers (wgrad partial slabs), one per (device, stream): reuse is stream-ordered."""
-        k = (key, device, torch.cuda.current_stream().cuda_stream)
+        k = (key, device, _raw_stream(_current_device()))
         buf = self._ws.get(k)
         if buf is None or buf.numel() < nfloats:
             buf = torch.empty(int(nfloats), dtype=_f32, device=device)

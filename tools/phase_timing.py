@@ -26,17 +26,31 @@ def mark(name):
     ev = torch.cuda.Event(enable_timing=True); ev.record()
     marks.append((name, time.perf_counter(), ev))
 
+bmarks = []
+def bmark(name):
+    def hook(grad):
+        ev = torch.cuda.Event(enable_timing=True); ev.record()
+        bmarks.append((name, time.perf_counter(), ev))
+        return grad
+    return hook
+
 unet_fwd = m.Unet_list.forward
 def unet_wrapped(*a, **k):
-    out = unet_fwd(*a, **k); mark("encoder (U-Net down path)"); return out
+    out = unet_fwd(*a, **k); mark("encoder (U-Net down path)")
+    if torch.is_grad_enabled():
+        out[3].register_hook(bmark("bwd: region pipelines done (grad of x4 ready)"))
+    return out
 m.Unet_list.forward = unet_wrapped
 enc = m.encode
 def enc_wrapped(*a, **k):
-    out = enc(*a, **k); mark("region pipelines + cross-region coupler"); return out
+    out = enc(*a, **k); mark("region pipelines + cross-region coupler")
+    if torch.is_grad_enabled():
+        out[3].register_hook(bmark("bwd: decoder + heads + losses done (grad of bottleneck ready)"))
+    return out
 m.encode = enc_wrapped
 
 for rep in range(2):
-    marks.clear()
+    marks.clear(); bmarks.clear()
     torch.cuda.synchronize()
     mark("start")
     outs = m(x, None); mark("decoder + heads")
@@ -50,4 +64,10 @@ print("%-45s %10s %10s" % ("phase", "host ms", "GPU ms"))
 for (n0, h0, e0), (n1, h1, e1) in zip(marks[:-1], marks[1:]):
     print("%-45s %10.2f %10.2f" % (n1, (h1 - h0) * 1e3, e0.elapsed_time(e1)))
 print("%-45s %10.2f %10.2f" % ("total", (marks[-1][1] - marks[0][1]) * 1e3, marks[0][2].elapsed_time(marks[-1][2])))
+loss_mark = [mk for mk in marks if mk[0] == "losses"][0]
+bwd_mark = [mk for mk in marks if mk[0] == "backward"][0]
+prev = loss_mark
+for name, h, ev in bmarks + [("bwd: encoder done", bwd_mark[1], bwd_mark[2])]:
+    print("  %-70s host +%6.2f ms   GPU +%6.2f ms" % (name, (h - prev[1]) * 1e3, prev[2].elapsed_time(ev)))
+    prev = (name, h, ev)
 print("wall incl. final sync: %.2f ms" % ((t_end - marks[0][1]) * 1e3))
