@@ -2,7 +2,7 @@
 // and their gradients), LayerNorm fwd/bwd, row softmax fwd/bwd, GELU backward, column sums.
 // Reference: SelfAttention.py:74-102 (DualSelfAttention), ResidualNorm.py:4-47, ClsWiseTransformer.py:41-55,
 // FusionClsWiseTransformer.py:43-54.  Sequence length is 129 / 258 tokens x 512: launch-latency bound, so the
-// kernels are kept simple (64x64x16 workgroup tiles, one pass).
+// kernels are kept simple (64x64 or 32x32 workgroup tiles, K steps of 32, one pass).
 #include "common.h"
 
 struct GemmArgs {
@@ -13,16 +13,19 @@ struct GemmArgs {
   int M, N, K, ZH; float alpha; int act; int accumulate;
 };
 
-#define GT 64
 #define GK 32
-#define LDA_S 33
-#define LDB_S 80
 
-// 64x64 output tile per workgroup, K in steps of 32.  The next K-tile is fetched into registers BEFORE the MFMAs of the
-// current one are issued (software pipelining): these GEMMs are tiny (M = 129..516 rows) and run at ~1 workgroup per CU, so
-// without the prefetch every K step pays a full L2 round trip.
+// TM x TN output tile per workgroup (64 x 64: each of the 4 waves owns 2 x 2 MFMA tiles; 32 x 32: one tile per wave), K in
+// steps of 32.  The next K-tile is fetched into registers BEFORE the MFMAs of the current one are issued (software
+// pipelining).  These GEMMs are tiny (M = 129..516 rows): with 64 x 64 tiles most of them launch 24-48 workgroups on a
+// 256-CU chip and each workgroup grinds through its K loop alone at the fp32 MFMA rate, so small problems use 32 x 32 tiles
+// (4x the workgroups, a quarter of the per-step MFMA time).
+template <int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs a) {
-  __shared__ float As[GT * LDA_S];
+  constexpr int LDA_S = GK + 1, LDB_S = TN + 16;
+  constexpr int IM = TM / 32, JN = TN / 32;             // MFMA tiles per wave
+  constexpr int SA = TM * GK / 256, SB = TN * GK / 256; // load slots per thread
+  __shared__ float As[TM * LDA_S];
   __shared__ float Bs[GK * LDB_S];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -30,29 +33,35 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs a) {
   const int zb = blockIdx.z / a.ZH, zh = blockIdx.z % a.ZH;
   const float* A = a.A + zb * a.sa_zb + zh * a.sa_zh;
   const float* B = a.B + zb * a.sb_zb + zh * a.sb_zh;
-  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
 
-  f32x4 acc[2][2];
+  f32x4 acc[IM][JN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < IM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < JN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const bool a_kfast = (a.sa_k == 1);
   const bool b_nfast = (a.sb_n == 1);
-  // element (m,k) / (k,n) handled by this thread in load slot i (8 slots each)
-  int am[8], ak[8], bk[8], bn[8];
+  // element (m,k) / (k,n) handled by this thread in load slot i
+  int am[SA], ak[SA], bk[SB], bn[SB];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    if (a_kfast) { ak[i] = tid & 31; am[i] = (tid >> 5) + 8 * i; } else { am[i] = tid & 63; ak[i] = (tid >> 6) + 4 * i; }
-    if (b_nfast) { bn[i] = tid & 63; bk[i] = (tid >> 6) + 4 * i; } else { bk[i] = tid & 31; bn[i] = (tid >> 5) + 8 * i; }
+  for (int i = 0; i < SA; ++i) {
+    if (a_kfast) { ak[i] = tid & 31; am[i] = (tid >> 5) + 8 * i; } else { am[i] = tid % TM; ak[i] = tid / TM + (256 / TM) * i; }
   }
-  float ra[8], rb[8];
+#pragma unroll
+  for (int i = 0; i < SB; ++i) {
+    if (b_nfast) { bn[i] = tid % TN; bk[i] = tid / TN + (256 / TN) * i; } else { bk[i] = tid & 31; bn[i] = (tid >> 5) + 8 * i; }
+  }
+  float ra[SA], rb[SB];
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < SA; ++i) {
       const int gm = m0 + am[i], gk = k0 + ak[i];
       ra[i] = (gm < a.M && gk < a.K) ? A[gm * a.sa_m + gk * a.sa_k] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
       const int gn = n0 + bn[i], gkb = k0 + bk[i];
       rb[i] = (gn < a.N && gkb < a.K) ? B[gkb * a.sb_k + gn * a.sb_n] : 0.f;
     }
@@ -61,34 +70,36 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs a) {
   for (int k0 = 0; k0 < a.K; k0 += GK) {
     if (k0) __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { As[am[i] * LDA_S + ak[i]] = ra[i]; Bs[bk[i] * LDB_S + bn[i]] = rb[i]; }
+    for (int i = 0; i < SA; ++i) As[am[i] * LDA_S + ak[i]] = ra[i];
+#pragma unroll
+    for (int i = 0; i < SB; ++i) Bs[bk[i] * LDB_S + bn[i]] = rb[i];
     __syncthreads();
     if (k0 + GK < a.K) fetch(k0 + GK);          // in flight while the MFMAs below run
 #pragma unroll
     for (int kk = 0; kk < GK / 4; ++kk) {
-      float av[2], bv[2];
+      float av[IM], bv[JN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) av[i] = As[(wr * 32 + i * 16 + r) * LDA_S + kk * 4 + kq];
+      for (int i = 0; i < IM; ++i) av[i] = As[(wr * (TM / 2) + i * 16 + r) * LDA_S + kk * 4 + kq];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bv[j] = Bs[(kk * 4 + kq) * LDB_S + wc * 32 + j * 16 + r];
+      for (int j = 0; j < JN; ++j) bv[j] = Bs[(kk * 4 + kq) * LDB_S + wc * (TN / 2) + j * 16 + r];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < IM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < JN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
   }
   float* C = a.C + zb * a.sc_zb + zh * a.sc_zh;
   const float* R = a.residual ? a.residual + zb * a.sr_zb + zh * a.sr_zh : nullptr;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < IM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int gn = n0 + wc * 32 + j * 16 + r;
+    for (int j = 0; j < JN; ++j) {
+      const int gn = n0 + wc * (TN / 2) + j * 16 + r;
       if (gn >= a.N) continue;
       const float bv = a.bias ? a.bias[gn] : 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int gm = m0 + wr * 32 + i * 16 + kq * 4 + e;
+        const int gm = m0 + wr * (TM / 2) + i * 16 + kq * 4 + e;
         if (gm >= a.M) continue;
         float v = acc[i][j][e] * a.alpha + bv;
         if (a.act == 1) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
@@ -109,8 +120,14 @@ extern "C" int cwf_gemm(const float* A, int64_t sa_m, int64_t sa_k, int64_t sa_z
   if ((int64_t)ZB * ZH > 65535) return CWF_E_TOOLARGE;
   GemmArgs a{A, sa_m, sa_k, sa_zb, sa_zh, B, sb_k, sb_n, sb_zb, sb_zh, C, sc_m, sc_zb, sc_zh,
              bias, residual, sr_m, sr_zb, sr_zh, M, Nn, K, ZH, alpha, act, accumulate};
-  dim3 grid(cdiv(Nn, GT), cdiv(M, GT), ZB * ZH);
-  hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), 0, cwf_stream(stream), a);
+  const int64_t wg64 = (int64_t)cdiv(Nn, 64) * cdiv(M, 64) * ZB * ZH;
+  if (wg64 >= 256) {
+    dim3 grid(cdiv(Nn, 64), cdiv(M, 64), ZB * ZH);
+    hipLaunchKernelGGL((gemm_mfma_kernel<64, 64>), grid, dim3(256), 0, cwf_stream(stream), a);
+  } else {
+    dim3 grid(cdiv(Nn, 32), cdiv(M, 32), ZB * ZH);
+    hipLaunchKernelGGL((gemm_mfma_kernel<32, 32>), grid, dim3(256), 0, cwf_stream(stream), a);
+  }
   CWF_LAUNCH_CHECK();
   return 0;
 }
