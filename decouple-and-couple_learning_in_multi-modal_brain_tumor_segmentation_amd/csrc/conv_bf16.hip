@@ -339,6 +339,14 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
 //   * tile geometry is compile-time (6x6x18 halo): LDS offsets are immediates; the loader keeps one precomputed
 //     voxel-relative offset per staging slot and adds it to a scalar tile base (no div/mod or 64-bit math per voxel).
 // ---------------------------------------------------------------------------------------------------
+// Tap order of the <= 16-channel 3x3x3 stride-1 layers (cwf/packing.py: _taps3_order16): position -> natural tap index
+// kd*9 + kh*3 + kw.  Pairs (2s, 2s+1): s = 0..8 (kw0, kw1) of row (kd, kh) = (s/3, s%3); s = 9..11 (kd0, kd1) of (kh = s-9,
+// kw2); s = 12 (kh0, kh1) of (kd2, kw2); s = 13 the single tap (2,2,2).
+__host__ __device__ constexpr int c16_tap(int pos) {
+  return pos < 18 ? ((pos >> 1) / 3) * 9 + ((pos >> 1) % 3) * 3 + (pos & 1)
+       : pos < 24 ? ((pos - 18) & 1) * 9 + ((pos - 18) >> 1) * 3 + 2
+       : pos == 24 ? 18 + 0 + 2 : pos == 25 ? 18 + 3 + 2 : 18 + 6 + 2;
+}
 #define C16_TD 4
 #define C16_TH 4
 #define C16_ID 6
@@ -400,22 +408,22 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
         for (int i = tid; i < 14 * 64; i += 256) wls[i] = a.wpk[(i >> 6) * 128 + (i & 63) * 2 + 1];
       }
     }
-    // ---- A-fragment addressing.  LDS byte address = buffer parity + per-lane base[m] + tap offset.  The tap pair (2s, 2s+1) of
-    // one K = 32 step is split over lane halves (lanes 32-63 take tap 2s+1), whose offset differs from tap 2s's by one of
-    // three constants (next kw / next kh / next kd) or 0 (last, unpaired tap).  Four classes x four M-tiles of per-lane bases
+    // ---- A-fragment addressing.  LDS byte address = buffer parity + per-lane base[m] + tap offset.  The two taps of
+    // one K = 32 step are split over lane halves (lanes 32-63 take the second), whose offset differs from the first's by one of
+    // three constants (next kw / next kh row / next kd plane: see c16_tap) or 0 (last, unpaired tap).  Four classes x four M-tiles of per-lane bases
     // stay in registers, so the tap offset is the ds_read immediate and the MFMA loop carries no address arithmetic: the
     // kernel is bound by each SIMD's vector-issue port, shared by its MFMA wave and its loader wave (an MFMA holds it for 8
     // of its 16 cycles, every other vector instruction for >= 4) -- instructions, not bytes, are what is being saved here.
-    constexpr int D_KW = 32, D_KH = (C16_IW - 2) * 32, D_KD = ((C16_IH - 2) * C16_IW - 2) * 32;
+    constexpr int D_KW = 32, D_ROW = C16_IW * 32, D_PLANE = C16_IH * C16_IW * 32;
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     typedef const u32x4_t __attribute__((address_space(3)))* lds_u4p;    // 32-bit LDS pointer formed from an integer address
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds4;
-    unsigned ab[4][4];                                   // [class: 0 = +kw, 1 = +kh, 2 = +kd, 3 = same tap][m]
+    unsigned ab[4][4];                                   // [class: 0 = +kw, 1 = +row (kh), 2 = +plane (kd), 3 = same tap][m]
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const unsigned base = lds_base + (((wave * C16_IH + m) * C16_IW + r) * 16 + (kq & 1) * 8) * 2;
-      ab[0][m] = base + (second ? D_KW : 0); ab[1][m] = base + (second ? D_KH : 0);
-      ab[2][m] = base + (second ? D_KD : 0); ab[3][m] = base;
+      ab[0][m] = base + (second ? D_KW : 0); ab[1][m] = base + (second ? D_ROW : 0);
+      ab[2][m] = base + (second ? D_PLANE : 0); ab[3][m] = base;
     }
     const float bv = (a.bias && r < g.Cout) ? a.bias[r] : 0.f;
     const f32x4 bias4 = {bv, bv, bv, bv};                // accumulators start from the bias (lane = output channel r)
@@ -479,9 +487,9 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
       u32x4_t fa[2][4], fl[2][4]; uint4 fb[2];
       auto load_step = [&](int s_, int b_) {
         if (X3) fb[b_] = wl[s_ * 64];
-        const int ta = 2 * s_;
+        const int ta = c16_tap(2 * s_);                      // natural index of the step's first tap (second: +kw / +kd / +kh)
         const int oa = (((ta / 9) * C16_IH + (ta / 3) % 3) * C16_IW + ta % 3) * 32;
-        const int cls = (ta == 26) ? 3 : (ta % 3 != 2) ? 0 : ((ta / 3) % 3 != 2) ? 1 : 2;
+        const int cls = s_ < 9 ? 0 : s_ < 12 ? 2 : s_ == 12 ? 1 : 3;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           fa[b_][m] = *(lds_u4p)(uintptr_t)(ab[cls][m] + (unsigned)oa);
@@ -881,6 +889,11 @@ extern "C" int cwf_conv_mfma_bf16(int op, int x3, const float* x, int x_ldc, con
   a.x = x; a.wpk = reinterpret_cast<const uint4*>(wpk16); a.bias = bias; a.y = y; a.in_scale = in_scale; a.in_shift = in_shift;
   a.in_slope = in_slope; a.residual = residual; a.r_ldc = r_ldc; a.out_scale = out_scale; a.stats = stats;
   hipStream_t st = cwf_stream(stream);
+  if (op == CWF_CONV3_S1 && Cin <= 16 && Cout <= 16) {      // these layers are packed in conv16's tap order (c16_tap)
+    int nat[27];
+    for (int t = 0; t < 27; ++t) nat[t] = a.g.tapofs[t];
+    for (int t = 0; t < 27; ++t) a.g.tapofs[t] = nat[c16_tap(t)];
+  }
   if (op == CWF_CONV3_S1 && Cin <= 16 && Cout <= 16 && (int64_t)Do * Ho * Wo >= 32768) {
     // full-resolution 16-channel convs: the persistent register-resident-weight kernel (tile 4x4x16)
     rc = cwf_build_geom(a.g, op, N, Di, Hi, Wi, Cin, x_ldc, Do, Ho, Wo, Cout, y_ldc, 16);

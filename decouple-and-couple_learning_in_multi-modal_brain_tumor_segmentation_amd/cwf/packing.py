@@ -45,6 +45,26 @@ def _taps3():
     return [(kd, kh, kw) for kd in range(3) for kh in range(3) for kw in range(3)]
 
 
+def _taps3_order16():
+    """Tap order of the split-bf16 kernels for 3x3x3 stride-1 layers with <= 16 input and <= 16 output channels (conv16 and
+    its small-volume stand-in): the two taps of a K = 32 MFMA step must differ by an offset that does not depend on the row's
+    position in conv16's ring of LDS rows, so pairs are (kw0, kw1) of one (kd, kh) row, then (kd0, kd1) of the kw = 2 taps,
+    then the two remaining row neighbours, then the single last tap.  Mirrored by kOrder16 in csrc/conv_bf16.hip."""
+    order = []
+    for kd in range(3):
+        for kh in range(3):
+            order += [(kd, kh, 0), (kd, kh, 1)]
+    for kh in range(3):
+        order += [(0, kh, 2), (1, kh, 2)]
+    order += [(2, 0, 2), (2, 1, 2), (2, 2, 2)]
+    assert sorted(order) == sorted(_taps3())
+    return order
+
+
+def _taps3_for(op, cin, cout):
+    return _taps3_order16() if (op == CONV3_S1 and cin <= 16 and cout <= 16) else _taps3()
+
+
 def _s2_dgrad_classes():
     out = []
     for c in range(8):
@@ -179,7 +199,7 @@ def _pack_map16(ncls_taps, cin, cout, src_index):
 
 def fwd_map16(op, cin, cout):
     if op in (CONV3_S1, CONV3_S2):
-        return _pack_map16([_taps3()], cin, cout, lambda c, k, ci, co: ((co * cin + ci) * 3 + k[0]) * 9 + k[1] * 3 + k[2])
+        return _pack_map16([_taps3_for(op, cin, cout)], cin, cout, lambda c, k, ci, co: ((co * cin + ci) * 3 + k[0]) * 9 + k[1] * 3 + k[2])
     if op == CONV1:
         return _pack_map16([[None]], cin, cout, lambda c, k, ci, co: co * cin + ci)
     if op == CONVT2:
@@ -193,7 +213,7 @@ def dgrad_map16(op, cin, cout, cout_alloc=None):
     def guard(f):
         return lambda c, k, ci, co: np.where(ci < cout, f(c, k, np.minimum(ci, cout - 1), co), -1)
     if op == CONV3_S1:
-        return _pack_map16([_taps3()], ca, cin,
+        return _pack_map16([_taps3_for(op, cin, cout)], ca, cin,
                            guard(lambda c, k, ci, co: ((ci * cin + co) * 3 + (2 - k[0])) * 9 + (2 - k[1]) * 3 + (2 - k[2])))
     if op == CONV1:
         return _pack_map16([[None]], ca, cin, guard(lambda c, k, ci, co: ci * cin + co))
