@@ -50,8 +50,8 @@ def usable_cores():
 
 
 # HBM bytes per launch of the dominant kernel measured with rocprofv3 --pmc (FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE),
-# profiles/round1_conv16_wgrad16_final_pmc.txt (last table): 2 x 199.8 MB + 270.5 MB.  Re-measure when the kernel changes.
-MEASURED_HBM_BYTES_CONV16 = {"bf16x3": 670.0e6, "bf16": None, "fp32": None}
+# profiles/round1_conv16_wgrad16_final_pmc.txt (conv16s, sliding window): 2 x 153.8 MB + 269.5 MB.  Re-measure when the kernel changes.
+MEASURED_HBM_BYTES_CONV16 = {"bf16x3": 577.0e6, "bf16": None, "fp32": None}
 MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0 / 3.0, "bf16": 2500.0}   # dense peaks; bf16x3 issues 3 MFMAs per product
 
 
@@ -94,7 +94,7 @@ def dominant_kernel_roofline(dev, precision, iters=20):
         out = {"kernel": "conv_mfma_kernel<4,1,4> (v_mfma_f32_16x16x4_f32) 3x3x3 16->16 @128^3 x2", "bound": "mfma",
                "achieved": round(tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4)}
     else:
-        out = {"kernel": "conv16_kernel<%s> (v_mfma_f32_16x16x32_bf16, fp32 storage) 3x3x3 16->16 @128^3 x2" % precision, "bound": "hbm",
+        out = {"kernel": "conv16s_kernel<%s> (v_mfma_f32_16x16x32_bf16, fp32 storage) 3x3x3 16->16 @128^3 x2" % precision, "bound": "hbm",
                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
     out.update({"traffic": MEASURED_HBM_BYTES_CONV16.get(precision), "avg_launch_ms": round(ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": flops,

@@ -10,6 +10,7 @@
 // Packed weights: [class][ci_chunk16][tap pair][co_tile16][lane64][hi 8 | lo 8] bf16 (cwf_gather_split_bf16).
 // Geometry, tiling, epilogue (bias / residual / out_scale / InstanceNorm statistics) are those of conv_mfma.hip.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -774,8 +775,427 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// conv16s: conv16 with a SLIDING WINDOW along H.  A workgroup walks a column of 4x4x16 tiles (fixed n, tile_d, tile_w,
+// increasing tile_h); the halo rows two neighbouring tiles share stay in LDS, so a tile stages 4 new rows per plane
+// (7 staging slots per loader thread) instead of 6 (11 slots): the loader waves -- the longer of the kernel's two per-tile
+// chains -- do 36 % less work (loads, converts, LDS writes).  LDS holds, per plane, a RING of 12 rows:
+//     input row j of a column segment (j = 0 at global row 4*th0 - 1) lives in slot (j + 2) % 12,
+// tile t reads rows 4t..4t+5 and the loader meanwhile writes rows 4t+6..4t+9 of tile t+1 (slots disjoint: 10 <= 12).
+// With t % 3 a compile-time phase (the tile loop is unrolled by three) every LDS offset is an immediate again; the tap
+// pairing of c16_tap keeps the second tap of a K = 32 step at a phase-independent offset except for the one (kh0, kh1) pair,
+// which gets two base registers (row + 1, or the ring wrap).  A column segment starts with all six rows new: it is preceded
+// by a loader-only "pre-tile" (element e = 0) that stages rows -2..1 exactly like any other 4-row block (the MFMA waves only
+// pass its barrier), so the ring simply keeps turning across segments and the loader has no special case at all
+// (cost: one extra 4-row block per segment, ~3 % at 128^3).  Elements u = 0, 1, 2, ... of a workgroup: new rows -> group u % 3.
+// Everything else (weights in registers, deferred epilogue, statistics in registers, XCD-aware work order) is conv16_kernel's.
+// ---------------------------------------------------------------------------------------------------
+#define C16_RH 12
+#define C16S_SLOTS 7                                     // ceil(6 planes * 4 rows * 18 / 64)
+#define C16S_HSLOTS 4                                    // ceil(6 planes * 2 rows * 18 / 64)
+
+struct C16sWork { int nseg, seg_len, hsplit, ncols; };
+static int g_conv16_diag_mode = 0;                   // diagnostics (cwf_debug_conv16_mode): 1 no stores, 2 no loads, 8 no epilogue
+
+template <bool X3>
+__global__ __launch_bounds__(512) void conv16s_kernel(const ConvArgsB a, const C16sWork wk) {
+  extern __shared__ float4 lds4[];
+  const ConvGeom& g = a.g;
+  constexpr int ROWB = C16_IW * 32;                    // bytes of one LDS row (18 voxels x 16 ch bf16)
+  constexpr int PLANEB = C16_RH * ROWB;                // one plane of the ring
+  constexpr int IMGB = C16_ID * PLANEB;                // one image (hi or lo): 41,472 B
+  unsigned short* lds = reinterpret_cast<unsigned short*>(lds4);
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds4;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = (int)gridDim.x, per = G >> 3;
+  const int first_seg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);      // segments first_seg + k*G
+  if (first_seg >= wk.nseg) return;
+  const int nk = (wk.nseg - first_seg + G - 1) / G;                      // segments of this workgroup
+  // segment sg -> (hseg, n, tile_d, tile_w), rows th0 .. th0+len-1
+  struct Seg { int n, tile_d, tile_w, th0, len; };
+  auto seg_of = [&](int k) __attribute__((always_inline)) {
+    Seg sgm;
+    const int sg = first_seg + k * G;
+    const int hseg = sg / wk.ncols; int col = sg - hseg * wk.ncols;
+    sgm.tile_w = col % g.tiles_w; col /= g.tiles_w;
+    sgm.tile_d = col % g.tiles_d; sgm.n = col / g.tiles_d;
+    sgm.th0 = hseg * wk.seg_len;
+    sgm.len = min(wk.seg_len, g.tiles_h - sgm.th0);
+    return sgm;
+  };
+
+  if (wave < 4) {
+    // =============================================================== MFMA waves
+    const int r = lane & 15, kq = lane >> 4;
+    const bool second = (kq >> 1) != 0;
+    uint4 bh[14];
+    const uint4* wl = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lds) + 2 * IMGB) + lane;
+    {
+      const uint4* wp = a.wpk + lane * 2;
+#pragma unroll
+      for (int s = 0; s < 14; ++s) bh[s] = wp[s * 128];
+      if (X3) {
+        uint4* wls = reinterpret_cast<uint4*>(reinterpret_cast<char*>(lds) + 2 * IMGB);
+        for (int i = tid; i < 14 * 64; i += 256) wls[i] = a.wpk[(i >> 6) * 128 + (i & 63) * 2 + 1];
+      }
+    }
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    typedef const u32x4_t __attribute__((address_space(3)))* lds_u4p;
+    // per-lane bases: plane `wave`, row slot 0, voxel r, channel half kq&1; second-half lanes carry the pair's offset
+    const unsigned bl = lds_base + (unsigned)(wave * PLANEB + r * 32 + (kq & 1) * 16);
+    const unsigned b_kw = bl + (second ? 32u : 0u);                      // (kw0, kw1) pairs
+    const unsigned b_pl = bl + (second ? (unsigned)PLANEB : 0u);         // (kd0, kd1) pairs
+    const unsigned b_up = bl + (second ? (unsigned)ROWB : 0u);           // (kh0, kh1) pair, next slot
+    const unsigned b_wr = bl + (second ? 0u : (unsigned)(11 * ROWB));    // (kh0, kh1) pair across the ring wrap (slot 11 -> 0): the
+                                                                         // immediate addresses the SECOND tap's row, first lanes add 11 rows
+    const float bv = (a.bias && r < g.Cout) ? a.bias[r] : 0.f;
+    const f32x4 bias4 = {bv, bv, bv, bv};
+    unsigned yofs[4], rofs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { yofs[i] = (unsigned)((kq * 4 + i) * g.y_ldc + r) * 4u; rofs[i] = (unsigned)((kq * 4 + i) * a.r_ldc + r) * 4u; }
+    float s1 = 0.f, s2 = 0.f;
+    int stat_n = seg_of(0).n;
+    float osc = 1.f; int osc_n = -1;
+    auto flush_stats = [&](int n_) __attribute__((always_inline)) {
+      float u1 = s1, u2 = s2;
+      u1 += __shfl_xor(u1, 16, 64); u1 += __shfl_xor(u1, 32, 64);
+      u2 += __shfl_xor(u2, 16, 64); u2 += __shfl_xor(u2, 32, 64);
+      if (kq == 0 && r < g.Cout) {
+        atomic_add_f64(a.stats + ((int64_t)n_ * g.Cout + r) * 2 + 0, (double)u1);
+        atomic_add_f64(a.stats + ((int64_t)n_ * g.Cout + r) * 2 + 1, (double)u2);
+      }
+      s1 = 0.f; s2 = 0.f;
+    };
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // prologue loads done: the loop's stores are never waited for
+
+    f32x4 prev[4]; float* prev_yb = nullptr; int pend = 0;               // deferred epilogue (see conv16_kernel)
+    auto drain = [&](auto HT) __attribute__((always_inline)) {
+      constexpr bool HAS_STATS = decltype(HT)::value;
+      unsigned yo[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { yo[i] = yofs[i]; asm volatile("" : "+v"(yo[i])); }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        char* ybm = reinterpret_cast<char*>(prev_yb + (int64_t)m * g.Wo * g.y_ldc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = prev[m][i];
+          *reinterpret_cast<float*>(ybm + yo[i]) = v;
+          if (HAS_STATS) { s1 += v; s2 = fmaf(v, v, s2); }
+        }
+      }
+    };
+
+    // one tile: MFMA phase (ring phase PH = t % 3 compile-time) with the previous tile's deferred epilogue, then this tile's
+    auto tile = [&](auto PH_, const Seg& sg, int t) __attribute__((always_inline)) {
+      constexpr int PH = decltype(PH_)::value;
+      asm volatile("s_barrier" ::: "memory");            // rows of tile t are complete
+      f32x4 acc[4];
+      u32x4_t fa[2][4], fl[2][4]; uint4 fb[2];
+      auto load_step = [&](int s_, int b_) __attribute__((always_inline)) {
+        if (X3) fb[b_] = wl[s_ * 64];
+        const int ta = c16_tap(2 * s_);
+        const int kd = ta / 9, kh = (ta / 3) % 3, kw = ta % 3;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int slot = (4 * PH + 10 + m + kh) % C16_RH;             // first tap's row slot (rows 0,1 of the tile: previous group)
+          unsigned base; int imm;
+          if (s_ < 9) { base = b_kw; imm = (kd * C16_RH + slot) * ROWB + kw * 32; }
+          else if (s_ < 12) { base = b_pl; imm = (kd * C16_RH + slot) * ROWB + kw * 32; }
+          else if (s_ == 12) {
+            const int slot2 = (slot + 1) % C16_RH;
+            if (slot2 == slot + 1) { base = b_up; imm = (kd * C16_RH + slot) * ROWB + kw * 32; }
+            else { base = b_wr; imm = (kd * C16_RH + slot2) * ROWB + kw * 32; }        // wrap: immediate = second tap's row (slot 0)
+          } else { base = bl; imm = (kd * C16_RH + slot) * ROWB + kw * 32; }
+          fa[b_][m] = *(lds_u4p)(uintptr_t)(base + (unsigned)imm);
+          if (X3) fl[b_][m] = *(lds_u4p)(uintptr_t)(base + (unsigned)(imm + IMGB));
+        }
+      };
+      auto phase = [&](auto PEND_) __attribute__((always_inline)) {
+        constexpr int PEND = decltype(PEND_)::value;
+        unsigned yo[4];
+        if (PEND) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { yo[i] = yofs[i]; asm volatile("" : "+v"(yo[i])); }
+        }
+        load_step(0, 0);
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+          if (s + 1 < 14) load_step(s + 1, (s + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][m]), __builtin_bit_cast(bf16x8, bh[s]), s == 0 ? bias4 : acc[m], 0, 0, 0);
+            if (X3) {
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][m]), __builtin_bit_cast(bf16x8, fb[s & 1]), acc[m], 0, 0, 0);
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fl[s & 1][m]), __builtin_bit_cast(bf16x8, bh[s]), acc[m], 0, 0, 0);
+            }
+            if (PEND != 0 && s < 4) {
+              char* ybm = reinterpret_cast<char*>(prev_yb + (int64_t)s * g.Wo * g.y_ldc);
+              const float v = prev[s][m];
+              *reinterpret_cast<float*>(ybm + yo[m]) = v;
+              if (PEND == 1) { s1 += v; s2 = fmaf(v, v, s2); }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      if (pend == 0) phase(std::integral_constant<int, 0>{});
+      else if (pend == 1) phase(std::integral_constant<int, 1>{});
+      else phase(std::integral_constant<int, 2>{});
+      pend = 0;
+      // ---- epilogue of this tile
+      const int n = sg.n;
+      const int od = sg.tile_d * C16_TD + wave, oh0 = (sg.th0 + t) * C16_TH, ow0 = sg.tile_w * 16;
+      if (a.stats && n != stat_n) { flush_stats(stat_n); stat_n = n; }
+      if (od < g.Do && !(a.diag_mode & 8)) {               // diag_mode 8: no epilogue (diagnostics)
+        const int64_t vox0 = (((int64_t)n * g.Do + od) * g.Ho + oh0) * g.Wo + ow0;
+        float* yb = a.y + vox0 * g.y_ldc;
+        const float* rb = a.residual ? a.residual + vox0 * a.r_ldc : nullptr;
+        const bool hs = a.out_scale != nullptr;
+        if (hs && n != osc_n) {
+          osc = r < g.Cout ? a.out_scale[(int64_t)n * g.Cout + r] : 1.f;
+          asm volatile("" :: "v"(osc));
+          osc_n = n;
+        }
+        const bool full = (oh0 + C16_TH <= g.Ho) && (ow0 + 16 <= g.Wo) && g.Cout == 16 && !(hs && rb);
+        if (full && !rb && !hs) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) prev[m] = acc[m];
+          prev_yb = yb; pend = a.stats ? 1 : 2;
+        } else if (full) {
+          if (hs) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] *= osc;
+          }
+          auto epi = [&](auto HR, auto HT) __attribute__((always_inline)) {
+            constexpr bool HAS_RES = decltype(HR)::value, HAS_STATS = decltype(HT)::value;
+            unsigned yo[4], ro[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { yo[i] = yofs[i]; asm volatile("" : "+v"(yo[i])); if (HAS_RES) { ro[i] = rofs[i]; asm volatile("" : "+v"(ro[i])); } }
+            float rv[4][4];
+            if (HAS_RES) {
+#pragma unroll
+              for (int m = 0; m < 4; ++m) {
+                const char* rbm = reinterpret_cast<const char*>(rb + (int64_t)m * g.Wo * a.r_ldc);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rv[m][i] = *reinterpret_cast<const float*>(rbm + ro[i]);
+              }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              char* ybm = reinterpret_cast<char*>(yb + (int64_t)m * g.Wo * g.y_ldc);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                float v = acc[m][i];
+                if (HAS_RES) v += rv[m][i];
+                *reinterpret_cast<float*>(ybm + yo[i]) = v;
+                if (HAS_STATS) { s1 += v; s2 = fmaf(v, v, s2); }
+              }
+            }
+          };
+          using T_ = std::true_type; using F_ = std::false_type;
+          const bool ht = a.stats != nullptr;
+          if (rb) { if (ht) epi(T_{}, T_{}); else epi(T_{}, F_{}); }
+          else    { if (ht) epi(F_{}, T_{}); else epi(F_{}, F_{}); }
+        } else {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const bool ok = r < g.Cout && oh0 + m < g.Ho && ow0 + kq * 4 + i < g.Wo;
+              if (!ok) continue;
+              const int eo = m * g.Wo;
+              float v = acc[m][i];
+              if (rb) v += rb[eo * a.r_ldc + (rofs[i] >> 2)];
+              v *= osc;
+              yb[eo * g.y_ldc + (yofs[i] >> 2)] = v;
+              s1 += v; s2 += v * v;
+            }
+          }
+        }
+      }
+    };
+
+    int u = 0;                                           // element counter of this workgroup (pre-tiles included)
+    for (int k = 0; k < nk; ++k) {
+      const Seg sg = seg_of(k);
+      asm volatile("s_barrier" ::: "memory");            // pre-tile: loader only
+      ++u;
+      for (int t = 0; t < sg.len; ++t, ++u) {
+        const int ph = u % 3;
+        if (ph == 0) tile(std::integral_constant<int, 0>{}, sg, t);
+        else if (ph == 1) tile(std::integral_constant<int, 1>{}, sg, t);
+        else tile(std::integral_constant<int, 2>{}, sg, t);
+      }
+    }
+    if (pend == 1) drain(std::true_type{}); else if (pend == 2) drain(std::false_type{});
+    if (a.stats) flush_stats(stat_n);
+  } else {
+    // =============================================================== loader waves
+    const int lt = tid - 256;
+    const int q = lt & 3, c = q * 4;
+    const bool cval = c < g.Cin && !(a.diag_mode & 2);   // diag_mode 2: no loads (diagnostics)
+    const bool has_norm = a.in_scale != nullptr;
+    const float slope = a.in_slope;
+    const bool plain = !has_norm && slope == 1.f;
+    const int HW = g.Hi * g.Wi;
+    // staging slots of the 4 new rows: voxel v -> (plane, row 0..3, w)
+    int rel[C16S_SLOTS]; unsigned lrel[C16S_SLOTS];
+#pragma unroll
+    for (int i = 0; i < C16S_SLOTS; ++i) {
+      const int v = (lt >> 2) + 64 * i;
+      const int pl = v / 72, r4 = (v % 72) / 18, w = v % 18;
+      rel[i] = (pl * HW + r4 * g.Wi + w) * g.x_ldc + c;
+      lrel[i] = (unsigned)((pl * C16_RH + r4) * ROWB + w * 32 + q * 8);
+    }
+    const bool last_ok = (lt >> 2) + 64 * (C16S_SLOTS - 1) < 432;
+    const unsigned full_mask = last_ok ? ((1u << C16S_SLOTS) - 1u) : ((1u << (C16S_SLOTS - 1)) - 1u);
+    float4 pre[2][C16S_SLOTS];
+    unsigned pre_inb[2] = {0u, 0u};
+    __builtin_amdgcn_s_setprio(1);
+    // flattened element iterator (k, e): e = 0 is the segment's pre-tile (rows -2..1), e >= 1 the tile t = e - 1
+    struct It { int k, e; };
+    auto next = [&](It it) __attribute__((always_inline)) { It o = it; if (it.e < seg_of(it.k).len) o.e = it.e + 1; else { o.k = it.k + 1; o.e = 0; } return o; };
+    struct Org { const float* base; bool interior; int id0, ih0, iw0, n; };
+    // origin of the 4 NEW rows of element (k, e): planes od0-1.., rows 4*(th0+e-1)+1.., cols ow0-1..
+    auto origin = [&](It it) __attribute__((always_inline)) {
+      const Seg sgm = seg_of(it.k);
+      Org o;
+      o.n = sgm.n;
+      o.id0 = sgm.tile_d * C16_TD - 1; o.ih0 = (sgm.th0 + it.e - 1) * C16_TH + 1; o.iw0 = sgm.tile_w * 16 - 1;
+      o.base = a.x + ((((int64_t)o.n * g.Di + o.id0) * g.Hi + o.ih0) * g.Wi + o.iw0) * g.x_ldc;
+      o.interior = o.id0 >= 0 && o.id0 + C16_ID <= g.Di && o.ih0 >= 0 && o.ih0 + 4 <= g.Hi && o.iw0 >= 0 && o.iw0 + C16_IW <= g.Wi;
+      return o;
+    };
+    float4 pre_sc[2], pre_sh[2];                         // the element's per-sample scale / shift travel with its register set
+    auto issue = [&](const Org& o, auto S) __attribute__((always_inline)) -> unsigned {
+      constexpr int SET = decltype(S)::value;
+      unsigned inb = 0;
+      if (o.interior) {
+#pragma unroll
+        for (int i = 0; i < C16S_SLOTS; ++i) {
+          const bool ok = cval && (i < C16S_SLOTS - 1 || last_ok);
+          const float* p = ok ? o.base + rel[i] : a.x;
+          pre[SET][i] = *reinterpret_cast<const float4*>(p);
+          inb |= ok ? (1u << i) : 0u;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < C16S_SLOTS; ++i) {
+          const int v = (lt >> 2) + 64 * i;
+          const int pl = v / 72, r4 = (v % 72) / 18, w = v % 18;
+          const int gd = o.id0 + pl, gh = o.ih0 + r4, gw = o.iw0 + w;
+          const bool ok = cval && (i < C16S_SLOTS - 1 || last_ok) &&
+                          (unsigned)gd < (unsigned)g.Di && (unsigned)gh < (unsigned)g.Hi && (unsigned)gw < (unsigned)g.Wi;
+          const float* p = ok ? o.base + rel[i] : a.x;
+          pre[SET][i] = *reinterpret_cast<const float4*>(p);
+          inb |= ok ? (1u << i) : 0u;
+        }
+      }
+      if (has_norm) {                                    // kernel-uniform; dummy address for lanes beyond Cin
+        const int cc = cval ? c : 0;
+        pre_sc[SET] = *reinterpret_cast<const float4*>(a.in_scale + (int64_t)o.n * g.Cin + cc);
+        pre_sh[SET] = *reinterpret_cast<const float4*>(a.in_shift + (int64_t)o.n * g.Cin + cc);
+      }
+      return inb;
+    };
+    // one float4 -> bf16 hi/lo -> LDS; PLAIN (no norm/activation) and SELECT (zero out-of-bounds voxels after the activation)
+    // are compile-time so that a staging slot is straight-line code
+    auto cvt_store = [&](float4 val, bool was, const float4& sc, const float4& sh, unsigned dst, auto PL, auto SEL) __attribute__((always_inline)) {
+      constexpr bool PLAIN = decltype(PL)::value, SELECT = decltype(SEL)::value;
+      float v0 = val.x, v1 = val.y, v2 = val.z, v3 = val.w;
+      if (!PLAIN) {
+        v0 = act01(fmaf(v0, sc.x, sh.x), slope); v1 = act01(fmaf(v1, sc.y, sh.y), slope);
+        v2 = act01(fmaf(v2, sc.z, sh.z), slope); v3 = act01(fmaf(v3, sc.w, sh.w), slope);
+      }
+      uint2 h, l;
+      if (X3) { split_bf16(v0, v1, h.x, l.x); split_bf16(v2, v3, h.y, l.y); }
+      else { h.x = pack_bf16(v0, v1); h.y = pack_bf16(v2, v3); l = make_uint2(0u, 0u); }
+      if (SELECT) { h.x = was ? h.x : 0u; h.y = was ? h.y : 0u; l.x = was ? l.x : 0u; l.y = was ? l.y : 0u; }
+      char* db = reinterpret_cast<char*>(lds);
+      *reinterpret_cast<uint2*>(db + dst) = h;
+      if (X3) *reinterpret_cast<uint2*>(db + dst + IMGB) = l;
+    };
+    // convert register set S into ring group GRP (slots 4*GRP .. 4*GRP+3)
+    auto convert = [&](auto S, auto GRP_) __attribute__((always_inline)) {
+      constexpr int SET = decltype(S)::value, GRP = decltype(GRP_)::value;
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_norm) { sc = pre_sc[SET]; sh = pre_sh[SET]; }
+      const unsigned inb = pre_inb[SET];
+      const bool allin = __ballot(inb != full_mask) == 0ull;
+      auto body = [&](auto PL, auto AI) __attribute__((always_inline)) {
+        constexpr bool ALLIN = decltype(AI)::value;
+#pragma unroll
+        for (int i = 0; i < C16S_SLOTS; ++i) {
+          if (i == C16S_SLOTS - 1 && !last_ok) continue;
+          cvt_store(pre[SET][i], (inb >> i) & 1u, sc, sh, lrel[i] + (unsigned)(GRP * 4 * ROWB), PL, std::integral_constant<bool, !ALLIN>{});
+        }
+      };
+      using T_ = std::true_type; using F_ = std::false_type;
+      if (plain) { if (allin) body(T_{}, T_{}); else body(T_{}, F_{}); }
+      else       { if (allin) body(F_{}, T_{}); else body(F_{}, F_{}); }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    auto convert_u = [&](int uu, auto S) __attribute__((always_inline)) {   // element number uu -> ring group uu % 3
+      const int grp = uu % 3;
+      if (grp == 0) convert(S, std::integral_constant<int, 0>{});
+      else if (grp == 1) convert(S, std::integral_constant<int, 1>{});
+      else convert(S, std::integral_constant<int, 2>{});
+    };
+    // Flattened element sequence of this workgroup; element number `it` uses register set it & 1 and two elements of loads are
+    // in flight (three sets in flight measured SLOWER: 0.265 vs 0.247 ms).  Same straight-line shape as conv16_kernel's loader
+    // (each parity arm converts one set, then refills that same set) so that the compiler keeps counted s_waitcnt vmcnt(N).
+    int niter = 0;
+    for (int k = 0; k < nk; ++k) niter += seg_of(k).len + 1;
+    It ti{0, 0};                                         // element whose loads are issued next
+    pre_inb[0] = issue(origin(ti), S0{}); ti = next(ti);
+    convert_u(0, S0{});
+    if (niter > 1) { pre_inb[1] = issue(origin(ti), S1{}); ti = next(ti); }
+    if (niter > 2) { pre_inb[0] = issue(origin(ti), S0{}); ti = next(ti); }
+    for (int it = 0; it < niter; ++it) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // element `it` handed over
+      if (it + 1 < niter) {
+        if ((it + 1) & 1) {
+          convert_u(it + 1, S1{});
+          if (it + 3 < niter) { pre_inb[1] = issue(origin(ti), S1{}); ti = next(ti); }
+        } else {
+          convert_u(it + 1, S0{});
+          if (it + 3 < niter) { pre_inb[0] = issue(origin(ti), S0{}); ti = next(ti); }
+        }
+      }
+    }
+  }
+}
+
+template <bool X3>
+static int launch_conv16s(const ConvArgsB& a, hipStream_t st) {
+  const ConvGeom& g = a.g;
+  C16sWork wk;
+  wk.ncols = g.N * g.tiles_d * g.tiles_w;
+  int hsplit = (256 + wk.ncols - 1) / wk.ncols;          // enough segments for 256 workgroups ...
+  if (hsplit > g.tiles_h / 3) hsplit = g.tiles_h / 3;    // ... but at least 3 tiles per segment (a segment start costs 2 extra rows)
+  if (hsplit < 1) hsplit = 1;
+  wk.seg_len = (g.tiles_h + hsplit - 1) / hsplit;
+  wk.hsplit = (g.tiles_h + wk.seg_len - 1) / wk.seg_len;
+  wk.nseg = wk.ncols * wk.hsplit;
+  const size_t lds = (size_t)2 * C16_ID * C16_RH * C16_IW * 32 + (X3 ? 14 * 64 * 16 : 0);   // hi + lo rings (+ lo weights)
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv16s_kernel<X3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  int grid = 256; while (grid > 8 && grid > wk.nseg) grid -= 8;
+  ConvArgsB aa = a; aa.diag = nullptr; aa.diag_mode = g_conv16_diag_mode;
+  hipLaunchKernelGGL((conv16s_kernel<X3>), dim3(grid), dim3(512), lds, st, aa, wk);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+
 static unsigned long long* g_conv16_diag = nullptr;
-static int g_conv16_diag_mode = 0;
 extern "C" void cwf_debug_conv16_diag(unsigned long long* buf) { g_conv16_diag = buf; }
 extern "C" void cwf_debug_conv16_mode(int m) { g_conv16_diag_mode = m; }   // diagnostic builds: 1 = no stores, 2 = no loads   // [256][8][4] u64, or NULL = off
 
@@ -898,6 +1318,9 @@ extern "C" int cwf_conv_mfma_bf16(int op, int x3, const float* x, int x_ldc, con
     // full-resolution 16-channel convs: the persistent register-resident-weight kernel (tile 4x4x16)
     rc = cwf_build_geom(a.g, op, N, Di, Hi, Wi, Cin, x_ldc, Do, Ho, Wo, Cout, y_ldc, 16);
     if (rc) return rc;
+    // sliding-window kernel by default; CWF_CONV16_NOSLIDE=1 selects the double-buffered full-halo kernel (A/B, diagnostics)
+    static const bool noslide = getenv("CWF_CONV16_NOSLIDE") != nullptr;
+    if (!noslide && !g_conv16_diag) return x3 ? launch_conv16s<true>(a, st) : launch_conv16s<false>(a, st);
     return x3 ? launch_conv16<true>(a, st) : launch_conv16<false>(a, st);
   }
 #define CWF_CFG(mt, nt, wm) if (c.MT == mt && c.NT == nt && c.WM == wm) return x3 ? launch_cfg<mt, nt, wm, true>(a, st) : launch_cfg<mt, nt, wm, false>(a, st);

@@ -32,6 +32,17 @@ for _ in range(iters): run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
 print("%s %s: %.4f ms  %.1f TFLOP/s alg  %.1f GB/s alg" % (what, prec, ms, 2.0 * 27 * c * c * n * s ** 3 / ms / 1e9, 2.0 * n * s ** 3 * c * 4 / ms / 1e6))
+if os.environ.get("CWF_SMODE"):
+    import ctypes
+    K.lib.cwf_debug_conv16_mode.argtypes = [ctypes.c_int]; K.lib.cwf_debug_conv16_mode.restype = None
+    for mode in (0, 2, 8, 10):
+        K.lib.cwf_debug_conv16_mode(mode)
+        run(); torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5): run()
+        e1.record(); torch.cuda.synchronize()
+        print("sliding kernel, mode %d (2 = no loads, 8 = no epilogue): %.4f ms" % (mode, e0.elapsed_time(e1) / 5))
+    K.lib.cwf_debug_conv16_mode(0)
 if os.environ.get("CWF_DIAG"):
     import ctypes
     diag = torch.zeros((256, 8, 4), dtype=torch.int64, device=dev)
