@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph of fwd+bwd instead of launching every kernel from "
                     "Python (host cost 1 ms instead of ~26 ms per step; currently slower end to end: the three sub-region streams "
                     "overlap in eager mode but a captured graph serialises more)")
+    ap.add_argument("--no-wgrad-async", action="store_true", help="keep the weight gradients on the main stream (A/B)")
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
                     help="MFMA operand form of the conv family (storage and accumulation are fp32 in every mode)")
     args = ap.parse_args()
@@ -167,7 +168,7 @@ def main():
 
     torch.manual_seed(1000 + rank)                       # train_no_amp.py:85 seed, per-rank streams
     model = get_cls_wise_former(dataset="brats", _conv_repr=True, _pe_type="fixed").to(dev).train()   # random init, dropout ON
-    trainer = Trainer(model, lr=2e-4, weight_decay=1e-5, amsgrad=True, end_epoch=1000, use_graph=args.graph)
+    trainer = Trainer(model, lr=2e-4, weight_decay=1e-5, amsgrad=True, end_epoch=1000, use_graph=args.graph, wgrad_async=not args.no_wgrad_async)
     size = (args.size,) * 3
     idx = [rank * args.batch + i for i in range(args.batch)]
     x, target, edge = syn.synthetic_batch(idx, size)

@@ -33,6 +33,7 @@ class ConvSpec:
         self.np_dgrad16 = pk.dgrad_map16(op, cin, cout, self.cout_alloc)
         self.np_inv, self.has_bias_map, self.slab = pk.wgrad_inverse_map(op, cin, cout)
         self.dev = None
+        self.uses = 0            # forward applications since the last WeightPacker.refresh() (= per model forward)
         self.fwd_map = self.dgrad_map = self.inv_map = self.fwd_map16 = self.dgrad_map16 = None
         self.wpk_f = self.wpk_d = self.wpk16_f = self.wpk16_d = None
 
@@ -72,6 +73,8 @@ class WeightPacker:
     def refresh(self):
         if not self.items:
             return
+        for spec, _ in self.items:
+            spec.uses = 0
         dev = self.items[0][1].device
         key = (dev, tuple(w.data_ptr() for _, w in self.items))
         if key != self._key:
@@ -99,6 +102,7 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x, w, b, spec, in_scale, in_shift, slope, residual, out_scale, want_stats):
         K = backend()
         n = x.shape[0]
+        spec.uses += 1
         stats = K.new_stats(n, spec.cout, x.device) if want_stats else None
         y = K.conv(spec.op, x, spec.packed(False), b, spec.cout, in_scale, in_shift, slope, residual, out_scale, stats,
                    w_ref=w, out_channels_alloc=spec.cout_alloc)
@@ -122,7 +126,13 @@ class _ConvFn(torch.autograd.Function):
         dw = db = dx = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dyv = dy[..., :spec.cout] if dy.shape[-1] != spec.cout else dy
-            dwf, db = K.wgrad(spec.op, x, in_scale, in_shift, ctx.slope, dyv, spec.cout, spec.inv_map, spec.has_bias_map, w.numel(), w_ref_shape=w.shape)
+            # side-stream weight gradients only where nothing on the main stream can touch their operands or results early:
+            #  * a weight applied twice in the forward, or a .grad that already exists, makes AccumulateGrad add IN PLACE;
+            #  * with a residual, dy itself is handed on as the residual's gradient and the engine may accumulate into it
+            #    in place while the side stream still reads it (record_stream guards reuse, not modification)
+            once = spec.uses <= 1 and w.grad is None and not ctx.has_res
+            dwf, db = K.wgrad(spec.op, x, in_scale, in_shift, ctx.slope, dyv, spec.cout, spec.inv_map, spec.has_bias_map, w.numel(), w_ref_shape=w.shape,
+                              allow_async=once)
             dw = dwf.view(w.shape)
             if db is None:      # ConvTranspose: bias gradient spans the 8 parity classes
                 db = K.in_stats(dy)[:, :, 0].sum(0).float()

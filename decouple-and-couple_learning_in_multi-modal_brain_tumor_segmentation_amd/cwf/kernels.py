@@ -73,6 +73,8 @@ class HipBackend:
         self._arena = {}
         self._arena_off = {}
         self._rng_counter = 0
+        self._wg_stream = {}                   # device -> side stream for weight gradients (opt-in, see wgrad_stream)
+        self.wgrad_async = False
         self._rng_lock = threading.Lock()      # the autograd engine may call in from its own thread
 
     # ------------------------------------------------------------------ helpers
@@ -155,7 +157,33 @@ class HipBackend:
                        _p(stats), n, di, hi, wi, cin, do, ho, wo, cout, self._stream())
         return y
 
-    def wgrad(self, op, x, in_scale, in_shift, slope, dy, cout, inv_map, has_bias_map, w_numel, w_ref_shape=None, prec=None):
+    # Weight gradients are leaves of the backward pass (only the optimizer reads them) while the data gradients form its
+    # critical path.  With `wgrad_async` (opt-in: the caller must call join_wgrad_stream() before reading any .grad -- the
+    # Trainer does) the weight-gradient kernels and their slab reductions go to a side stream and overlap the dgrad chain.
+    def wgrad_stream(self, device):
+        st = self._wg_stream.get(device)
+        if st is None:
+            st = torch.cuda.Stream(device=device)
+            self._wg_stream[device] = st
+        return st
+
+    def join_wgrad_stream(self):
+        for st in self._wg_stream.values():
+            torch.cuda.current_stream(st.device).wait_stream(st)
+
+    def wgrad(self, op, x, in_scale, in_shift, slope, dy, cout, inv_map, has_bias_map, w_numel, w_ref_shape=None, prec=None, allow_async=False):
+        if self.wgrad_async and allow_async and not torch.cuda.is_current_stream_capturing():
+            side = self.wgrad_stream(x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side):
+                out = self._wgrad_impl(op, x, in_scale, in_shift, slope, dy, cout, inv_map, has_bias_map, w_numel, w_ref_shape, prec)
+            for t in (x, dy, in_scale, in_shift):
+                if t is not None:
+                    t.record_stream(side)
+            return out
+        return self._wgrad_impl(op, x, in_scale, in_shift, slope, dy, cout, inv_map, has_bias_map, w_numel, w_ref_shape, prec)
+
+    def _wgrad_impl(self, op, x, in_scale, in_shift, slope, dy, cout, inv_map, has_bias_map, w_numel, w_ref_shape=None, prec=None):
         """returns (dW flat [w_numel], db [cout] or None)"""
         x, x_ldc = cl(x)
         dy, dy_ldc = cl(dy)

@@ -90,7 +90,7 @@ class EmulBackend:
         out.copy_(g)
         return out
 
-    def wgrad(self, op, x, in_scale, in_shift, slope, dy, cout, inv_map, has_bias_map, w_numel, w_ref_shape=None, prec=None):
+    def wgrad(self, op, x, in_scale, in_shift, slope, dy, cout, inv_map, has_bias_map, w_numel, w_ref_shape=None, prec=None, allow_async=False):
         """cwf_wgrad_mfma + cwf_wgrad_reduce: weight / bias halves of aten::convolution_backward on act(IN(x))."""
         xa = _prologue(x, in_scale, in_shift, slope).detach()
         w = torch.zeros(w_ref_shape, dtype=torch.float32, requires_grad=True)

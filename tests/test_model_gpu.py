@@ -228,3 +228,35 @@ def test_training_harness_on_gpu(hip, tmp_path):
     assert len(ck["state_dict"]) == 222 and all(k.startswith("module.") for k in ck["state_dict"])
     from cwf import kernels
     kernels.set_precision("fp32")
+
+
+def test_wgrad_side_stream_gives_same_gradients(hip):
+    """Trainer(wgrad_async=True) runs the weight-gradient kernels of single-use conv weights on a side stream.  Token selection
+    is teacher-forced (a top-k flip from reduction-order noise would change the gradients wholesale); what remains
+    between two runs of the SAME configuration is ~3e-6 relative (float atomics in the token reductions), so "same" means
+    within that noise (tools/wg_async_check.py prints all three pairings)."""
+    from cwf.trainer import Trainer
+    xc, target, edge = syn.synthetic_batch([0], (64, 64, 64))
+    with torch.no_grad():
+        _, aux = rm.forward(syn.det_state_dict(rm.param_shapes()), xc, return_aux=True)
+    forced = {k: v.to(DEV) for k, v in aux.items() if v.dtype == torch.int64}
+    x, target, edge = xc.to(DEV), target.to(DEV), edge.to(DEV)
+    flats = []
+    for flag in (False, True, False):
+        m = _model().train()
+        m.forced_index = forced
+        m.Unet_list.InitConv.dropout = 0.0
+        for mod in m.modules():                     # no dropout anywhere
+            if hasattr(mod, "dropout_rate"):
+                mod.dropout_rate = 0.0
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        tr = Trainer(m, wgrad_async=flag)
+        assert tr.wgrad_async == flag
+        tr._fwd_bwd(x, target, edge)
+        torch.cuda.synchronize()
+        flats.append(tr.opt.flat_grad.clone())
+    noise = float((flats[0] - flats[2]).norm() / flats[0].norm())          # sync vs sync
+    diff = float((flats[0] - flats[1]).norm() / flats[0].norm())           # sync vs side stream
+    assert float(flats[0].abs().sum()) > 0 and bool(torch.isfinite(flats[1]).all())
+    assert diff < max(5e-5, 10 * noise), (diff, noise)
