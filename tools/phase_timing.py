@@ -56,7 +56,9 @@ for rep in range(2):
     outs = m(x, None); mark("decoder + heads")
     loss, parts = total_loss(outs, target, edge); mark("losses")
     tr.opt.zero_grad()
-    loss.backward(); mark("backward")
+    from cwf.kernels import backend as _b
+    _b().wgrad_async = True
+    loss.backward(); _b().wgrad_async = False; _b().join_wgrad_stream(); mark("backward")
     tr.opt.step(); mark("adam")
     torch.cuda.synchronize()
     t_end = time.perf_counter()
