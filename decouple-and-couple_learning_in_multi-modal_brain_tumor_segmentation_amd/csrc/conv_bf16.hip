@@ -21,6 +21,10 @@ struct ConvArgsB {
   const float* in_scale; const float* in_shift; float in_slope;
   const float* residual; int r_ldc; const float* out_scale; double* stats;
   unsigned long long* diag; int diag_mode;
+  // "norm-backward" statistics (data-gradient launches whose output g feeds the backward of y = act(IN(x))): with nb_x set,
+  // stats receives per (n, channel)  S1 = sum g*act'(h), S2 = sum g*act'(h)*h,  h = nb_x*nb_scale + nb_shift  -- what
+  // cwf_in_bwd_stats would compute in a separate pass over g and x (norm.hip) -- instead of (sum y, sum y^2).
+  const float* nb_x; int nb_ldc; const float* nb_scale; const float* nb_shift; float nb_slope;
 };
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -238,13 +242,22 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
         bvj[j] = 0.f;
       }
     }
-    auto epi = [&](auto HR, auto HT) {
-      constexpr bool HAS_RES = decltype(HR)::value, HAS_STATS = decltype(HT)::value;
-      unsigned yo[4], ro[4];
+    auto epi = [&](auto HR, auto HT, auto HN) {
+      constexpr bool HAS_RES = decltype(HR)::value, HAS_STATS = decltype(HT)::value, HAS_NB = decltype(HN)::value;
+      unsigned yo[4], ro[4], xo[4];
+      float nsc[NT], nsh[NT];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {                      // opaque copies: keep the zero-extension in this block (saddr form)
         yo[i] = (unsigned)((kq * 4 + i) * g.y_ldc + nt0 * 16 + r) * 4u; asm volatile("" : "+v"(yo[i]));
         if (HAS_RES) { ro[i] = (unsigned)((kq * 4 + i) * a.r_ldc + nt0 * 16 + r) * 4u; asm volatile("" : "+v"(ro[i])); }
+        if (HAS_NB) { xo[i] = (unsigned)((kq * 4 + i) * a.nb_ldc + nt0 * 16 + r) * 4u; asm volatile("" : "+v"(xo[i])); }
+      }
+      if (HAS_NB) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          nsc[j] = a.nb_scale[(int64_t)n * g.Cout + (nt0 + j) * 16 + r];
+          nsh[j] = a.nb_shift[(int64_t)n * g.Cout + (nt0 + j) * 16 + r];
+        }
       }
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -253,12 +266,19 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
         const int64_t vox0 = (((int64_t)n * g.Do + od) * g.Ho + oh) * g.Wo + ow0;
         char* yb = reinterpret_cast<char*>(a.y + vox0 * g.y_ldc);
         const char* rb = HAS_RES ? reinterpret_cast<const char*>(a.residual + vox0 * a.r_ldc) : nullptr;
-        float rv[NT][4];
+        const char* xb = HAS_NB ? reinterpret_cast<const char*>(a.nb_x + vox0 * a.nb_ldc) : nullptr;
+        float rv[NT][4], xv[NT][4];
         if (HAS_RES) {
 #pragma unroll
           for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) rv[j][i] = *reinterpret_cast<const float*>(rb + ro[i] + j * 64);
+        }
+        if (HAS_NB) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xv[j][i] = *reinterpret_cast<const float*>(xb + xo[i] + j * 64);
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j)
@@ -267,13 +287,18 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
             float v = acc[m][j][i] + bvj[j];
             if (HAS_RES) v += rv[j][i];
             *reinterpret_cast<float*>(yb + yo[i] + j * 64) = v;
-            if (HAS_STATS) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
+            if (HAS_NB) {
+              const float h = fmaf(xv[j][i], nsc[j], nsh[j]);
+              const float gn = v * (h > 0.f ? 1.f : a.nb_slope);
+              s1[j] += gn; s2[j] = fmaf(gn, h, s2[j]);
+            } else if (HAS_STATS) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
           }
       }
     };
     using T_ = std::true_type; using F_ = std::false_type;
-    if (a.residual) { if (a.stats) epi(T_{}, T_{}); else epi(T_{}, F_{}); }
-    else            { if (a.stats) epi(F_{}, T_{}); else epi(F_{}, F_{}); }
+    if (a.nb_x) { if (a.residual) epi(T_{}, T_{}, T_{}); else epi(F_{}, T_{}, T_{}); }
+    else if (a.residual) { if (a.stats) epi(T_{}, T_{}, F_{}); else epi(T_{}, F_{}, F_{}); }
+    else            { if (a.stats) epi(F_{}, T_{}, F_{}); else epi(F_{}, F_{}, F_{}); }
   } else {
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -295,7 +320,11 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
         if (a.residual) v += a.residual[vox * a.r_ldc + co];
         v *= osc;
         a.y[vox * g.y_ldc + co] = v;
-        s1[j] += v; s2[j] += v * v;
+        if (a.nb_x) {
+          const float h = fmaf(a.nb_x[vox * a.nb_ldc + co], a.nb_scale[(int64_t)n * g.Cout + co], a.nb_shift[(int64_t)n * g.Cout + co]);
+          const float gn = v * (h > 0.f ? 1.f : a.nb_slope);
+          s1[j] += gn; s2[j] += gn * h;
+        } else { s1[j] += v; s2[j] += v * v; }
       }
     }
   }
@@ -960,8 +989,14 @@ __global__ __launch_bounds__(512) void conv16s_kernel(const ConvArgsB a, const C
           asm volatile("" :: "v"(osc));
           osc_n = n;
         }
+        // norm-backward statistics (nb launches only; they take the immediate epilogue, so nothing of this lives across tiles --
+        // the MFMA waves have no register to spare)
+        const bool nb = a.nb_x != nullptr;
+        const float* xbn = nb ? a.nb_x + vox0 * a.nb_ldc : nullptr;
+        float nsc = 0.f, nsh = 0.f;
+        if (nb && r < g.Cout) { nsc = a.nb_scale[(int64_t)n * g.Cout + r]; nsh = a.nb_shift[(int64_t)n * g.Cout + r]; }
         const bool full = (oh0 + C16_TH <= g.Ho) && (ow0 + 16 <= g.Wo) && g.Cout == 16 && !(hs && rb);
-        if (full && !rb && !hs) {
+        if (full && !rb && !hs && !nb) {
 #pragma unroll
           for (int m = 0; m < 4; ++m) prev[m] = acc[m];
           prev_yb = yb; pend = a.stats ? 1 : 2;
@@ -970,11 +1005,24 @@ __global__ __launch_bounds__(512) void conv16s_kernel(const ConvArgsB a, const C
 #pragma unroll
             for (int m = 0; m < 4; ++m) acc[m] *= osc;
           }
-          auto epi = [&](auto HR, auto HT) __attribute__((always_inline)) {
-            constexpr bool HAS_RES = decltype(HR)::value, HAS_STATS = decltype(HT)::value;
-            unsigned yo[4], ro[4];
+          auto epi = [&](auto HR, auto HT, auto HN) __attribute__((always_inline)) {
+            constexpr bool HAS_RES = decltype(HR)::value, HAS_STATS = decltype(HT)::value, HAS_NB = decltype(HN)::value;
+            unsigned yo[4], ro[4], xo[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { yo[i] = yofs[i]; asm volatile("" : "+v"(yo[i])); if (HAS_RES) { ro[i] = rofs[i]; asm volatile("" : "+v"(ro[i])); } }
+            for (int i = 0; i < 4; ++i) {
+              yo[i] = yofs[i]; asm volatile("" : "+v"(yo[i]));
+              if (HAS_RES) { ro[i] = rofs[i]; asm volatile("" : "+v"(ro[i])); }
+              if (HAS_NB) { xo[i] = (unsigned)((kq * 4 + i) * a.nb_ldc + r) * 4u; asm volatile("" : "+v"(xo[i])); }
+            }
+            float xv[4][4];
+            if (HAS_NB) {
+#pragma unroll
+              for (int m = 0; m < 4; ++m) {
+                const char* xbm = reinterpret_cast<const char*>(xbn + (int64_t)m * g.Wo * a.nb_ldc);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xv[m][i] = *reinterpret_cast<const float*>(xbm + xo[i]);
+              }
+            }
             float rv[4][4];
             if (HAS_RES) {
 #pragma unroll
@@ -992,14 +1040,19 @@ __global__ __launch_bounds__(512) void conv16s_kernel(const ConvArgsB a, const C
                 float v = acc[m][i];
                 if (HAS_RES) v += rv[m][i];
                 *reinterpret_cast<float*>(ybm + yo[i]) = v;
-                if (HAS_STATS) { s1 += v; s2 = fmaf(v, v, s2); }
+                if (HAS_NB) {
+                  const float h = fmaf(xv[m][i], nsc, nsh);
+                  const float gn = v * (h > 0.f ? 1.f : a.nb_slope);
+                  s1 += gn; s2 = fmaf(gn, h, s2);
+                } else if (HAS_STATS) { s1 += v; s2 = fmaf(v, v, s2); }
               }
             }
           };
           using T_ = std::true_type; using F_ = std::false_type;
           const bool ht = a.stats != nullptr;
-          if (rb) { if (ht) epi(T_{}, T_{}); else epi(T_{}, F_{}); }
-          else    { if (ht) epi(F_{}, T_{}); else epi(F_{}, F_{}); }
+          if (nb) { if (rb) epi(T_{}, T_{}, T_{}); else epi(F_{}, T_{}, T_{}); }
+          else if (rb) { if (ht) epi(T_{}, T_{}, F_{}); else epi(T_{}, F_{}, F_{}); }
+          else    { if (ht) epi(F_{}, T_{}, F_{}); else epi(F_{}, F_{}, F_{}); }
         } else {
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
@@ -1012,7 +1065,11 @@ __global__ __launch_bounds__(512) void conv16s_kernel(const ConvArgsB a, const C
               if (rb) v += rb[eo * a.r_ldc + (rofs[i] >> 2)];
               v *= osc;
               yb[eo * g.y_ldc + (yofs[i] >> 2)] = v;
-              s1 += v; s2 += v * v;
+              if (nb) {
+                const float h = fmaf(xbn[eo * a.nb_ldc + (kq * 4 + i) * a.nb_ldc + r], nsc, nsh);
+                const float gn = v * (h > 0.f ? 1.f : a.nb_slope);
+                s1 += gn; s2 += gn * h;
+              } else { s1 += v; s2 += v * v; }
             }
           }
         }
@@ -1291,11 +1348,27 @@ int launch_cfg(const ConvArgsB& a, hipStream_t st) {
 }
 }  // namespace
 
+extern "C" int cwf_conv_mfma_bf16_nb(int op, int x3, const float* x, int x_ldc, const void* wpk16, const float* bias,
+                                     float* y, int y_ldc, const float* in_scale, const float* in_shift, float in_slope,
+                                     const float* residual, int r_ldc, const float* out_scale, double* stats,
+                                     const float* nb_x, int nb_ldc, const float* nb_scale, const float* nb_shift, float nb_slope,
+                                     int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, void* stream);
+
 extern "C" int cwf_conv_mfma_bf16(int op, int x3, const float* x, int x_ldc, const void* wpk16, const float* bias,
                                   float* y, int y_ldc, const float* in_scale, const float* in_shift, float in_slope,
                                   const float* residual, int r_ldc, const float* out_scale, double* stats,
                                   int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, void* stream) {
+  return cwf_conv_mfma_bf16_nb(op, x3, x, x_ldc, wpk16, bias, y, y_ldc, in_scale, in_shift, in_slope, residual, r_ldc, out_scale, stats,
+                               nullptr, 0, nullptr, nullptr, 1.f, N, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, stream);
+}
+
+extern "C" int cwf_conv_mfma_bf16_nb(int op, int x3, const float* x, int x_ldc, const void* wpk16, const float* bias,
+                                     float* y, int y_ldc, const float* in_scale, const float* in_shift, float in_slope,
+                                     const float* residual, int r_ldc, const float* out_scale, double* stats,
+                                     const float* nb_x, int nb_ldc, const float* nb_scale, const float* nb_shift, float nb_slope,
+                                     int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, void* stream) {
   if (!x || !wpk16 || !y || N <= 0 || Cin <= 0 || Cout <= 0) return CWF_E_BADARG;
+  if (nb_x && (!stats || !nb_scale || !nb_shift || nb_ldc < Cout)) return CWF_E_BADARG;
   if ((Cin & 3) || (x_ldc & 3) || x_ldc < Cin || y_ldc < Cout) return CWF_E_ALIGN;
   if (((uintptr_t)x & 15) || ((uintptr_t)wpk16 & 15)) return CWF_E_ALIGN;
   if (in_scale && !in_shift) return CWF_E_BADARG;
@@ -1308,6 +1381,8 @@ extern "C" int cwf_conv_mfma_bf16(int op, int x3, const float* x, int x_ldc, con
   if (rc) return rc;
   a.x = x; a.wpk = reinterpret_cast<const uint4*>(wpk16); a.bias = bias; a.y = y; a.in_scale = in_scale; a.in_shift = in_shift;
   a.in_slope = in_slope; a.residual = residual; a.r_ldc = r_ldc; a.out_scale = out_scale; a.stats = stats;
+  a.nb_x = nb_x; a.nb_ldc = nb_ldc; a.nb_scale = nb_scale; a.nb_shift = nb_shift; a.nb_slope = nb_slope;
+  a.diag = nullptr; a.diag_mode = 0;
   hipStream_t st = cwf_stream(stream);
   if (op == CWF_CONV3_S1 && Cin <= 16 && Cout <= 16) {      // these layers are packed in conv16's tap order (c16_tap)
     int nat[27];
@@ -1320,7 +1395,7 @@ extern "C" int cwf_conv_mfma_bf16(int op, int x3, const float* x, int x_ldc, con
     if (rc) return rc;
     // sliding-window kernel by default; CWF_CONV16_NOSLIDE=1 selects the double-buffered full-halo kernel (A/B, diagnostics)
     static const bool noslide = getenv("CWF_CONV16_NOSLIDE") != nullptr;
-    if (!noslide && !g_conv16_diag) return x3 ? launch_conv16s<true>(a, st) : launch_conv16s<false>(a, st);
+    if ((!noslide && !g_conv16_diag) || nb_x) return x3 ? launch_conv16s<true>(a, st) : launch_conv16s<false>(a, st);   // (conv16 has no nb epilogue)
     return x3 ? launch_conv16<true>(a, st) : launch_conv16<false>(a, st);
   }
 #define CWF_CFG(mt, nt, wm) if (c.MT == mt && c.NT == nt && c.WM == wm) return x3 ? launch_cfg<mt, nt, wm, true>(a, st) : launch_cfg<mt, nt, wm, false>(a, st);

@@ -138,11 +138,16 @@ class _ConvFn(torch.autograd.Function):
                 db = K.in_stats(dy)[:, :, 0].sum(0).float()
         if ctx.needs_input_grad[0]:
             dxa = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-            K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op)
-            if in_scale is not None:
-                dx = K.in_bwd(dxa, x, in_scale, in_shift, ctx.slope)
+            fused = in_scale is not None and getattr(K, "supports_fused_norm_bwd", lambda: False)()
+            if fused:
+                # the InstanceNorm-backward sums come out of the data gradient's epilogue: one pass over (g, x) less
+                sums = K.new_stats(x.shape[0], spec.cin, x.device)
+                K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op,
+                       stats=sums, nb=(x, in_scale, in_shift, ctx.slope))
+                dx = K.in_bwd_apply(dxa, x, in_scale, in_shift, ctx.slope, sums)
             else:
-                dx = dxa
+                K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op)
+                dx = K.in_bwd(dxa, x, in_scale, in_shift, ctx.slope) if in_scale is not None else dxa
         return dx, dw, db, None, None, None, None, dres, None, None
 
 

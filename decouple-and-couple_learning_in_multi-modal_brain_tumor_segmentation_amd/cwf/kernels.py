@@ -127,7 +127,7 @@ class HipBackend:
 
     # ------------------------------------------------------------------ K1
     def conv(self, op, x, wpk, bias, cout, in_scale=None, in_shift=None, slope=1.0, residual=None, out_scale=None,
-             stats=None, out=None, w_ref=None, out_channels_alloc=None, fwd_op=None, prec=None):
+             stats=None, out=None, w_ref=None, out_channels_alloc=None, fwd_op=None, prec=None, nb=None):
         """Returns the output buffer.  With out_channels_alloc > cout the buffer has zero-filled padding channels
         (2-channel heads live in 4-channel tensors so that every later kernel sees 16-byte voxel rows).
         w_ref / fwd_op are ignored here (the test emulation uses them instead of the packed weights)."""
@@ -151,11 +151,36 @@ class HipBackend:
             self._call("cwf_conv_mfma", op, x.data_ptr(), x_ldc, wpk.data_ptr(), _p(bias), y.data_ptr(), y_ldc,
                        _p(in_scale), _p(in_shift), float(slope), _p(residual), r_ldc, _p(out_scale), _p(stats),
                        n, di, hi, wi, cin, do, ho, wo, cout, self._stream())
+        elif nb is not None:
+            # data gradient whose output feeds the backward of act(IN(nb_x)): stats := (S1, S2) of that backward (see in_bwd_fused)
+            nb_x, nb_scale, nb_shift, nb_slope = nb
+            nb_x, nb_ldc = cl(nb_x)
+            self._call("cwf_conv_mfma_bf16_nb", op, 1 if mode == "bf16x3" else 0, x.data_ptr(), x_ldc, wpk.data_ptr(), _p(bias),
+                       y.data_ptr(), y_ldc, _p(in_scale), _p(in_shift), float(slope), _p(residual), r_ldc, _p(out_scale),
+                       _p(stats), nb_x.data_ptr(), nb_ldc, nb_scale.data_ptr(), nb_shift.data_ptr(), float(nb_slope),
+                       n, di, hi, wi, cin, do, ho, wo, cout, self._stream())
         else:
             self._call("cwf_conv_mfma_bf16", op, 1 if mode == "bf16x3" else 0, x.data_ptr(), x_ldc, wpk.data_ptr(), _p(bias),
                        y.data_ptr(), y_ldc, _p(in_scale), _p(in_shift), float(slope), _p(residual), r_ldc, _p(out_scale),
                        _p(stats), n, di, hi, wi, cin, do, ho, wo, cout, self._stream())
         return y
+
+    def supports_fused_norm_bwd(self, prec=None):
+        """The split-bf16 conv kernels can accumulate the InstanceNorm-backward sums in the data-gradient epilogue."""
+        return (prec or _PRECISION) != "fp32"
+
+    def in_bwd_apply(self, dy, x, scale, shift, slope, sums, dx_add=None):
+        """Second half of in_bwd, given the (S1, S2) sums (from the data-gradient epilogue, conv(..., nb=...))."""
+        dy, dy_ldc = cl(dy)
+        x, x_ldc = cl(x)
+        n, d, h, w, c = x.shape
+        dx = torch.empty((n, d, h, w, c), dtype=_f32, device=x.device)
+        a_ldc = 0
+        if dx_add is not None:
+            dx_add, a_ldc = cl(dx_add)
+        self._call("cwf_in_bwd_apply", dy.data_ptr(), dy_ldc, x.data_ptr(), x_ldc, scale.data_ptr(), shift.data_ptr(), float(slope),
+                   sums.data_ptr(), _p(dx_add), a_ldc, dx.data_ptr(), c, n, d * h * w, c, self._stream())
+        return dx
 
     # Weight gradients are leaves of the backward pass (only the optimizer reads them) while the data gradients form its
     # critical path.  With `wgrad_async` (opt-in: the caller must call join_wgrad_stream() before reading any .grad -- the

@@ -96,6 +96,18 @@ int cwf_conv_mfma_bf16(int op, int x3,
                        const float* residual, int r_ldc, const float* out_scale, double* stats,
                        int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
                        void* stream);
+/* Same, with "norm-backward" statistics for data-gradient launches whose output g is the gradient of act(IN(x)) (the fused
+ * prologue of the forward conv, Unet_skipconnection.py:31-77 / cls_wise_former.py:157-204): with nb_x set, stats receives per
+ * (n, channel)  S1 = sum g*act'(h), S2 = sum g*act'(h)*h  with h = nb_x*nb_scale + nb_shift -- exactly what cwf_in_bwd_stats
+ * computes in a separate pass over g and x -- so that only cwf_in_bwd_apply remains of the InstanceNorm backward. */
+int cwf_conv_mfma_bf16_nb(int op, int x3,
+                          const float* x, int x_ldc, const void* wpk16, const float* bias,
+                          float* y, int y_ldc,
+                          const float* in_scale, const float* in_shift, float in_slope,
+                          const float* residual, int r_ldc, const float* out_scale, double* stats,
+                          const float* nb_x, int nb_ldc, const float* nb_scale, const float* nb_shift, float nb_slope,
+                          int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+                          void* stream);
 int cwf_wgrad_mfma_bf16(int op, int x3,
                         const float* x, int x_ldc, const float* in_scale, const float* in_shift, float in_slope,
                         const float* dy, int dy_ldc, float* partial,

@@ -116,6 +116,41 @@ def test_conv_family_fwd_dgrad_wgrad(hip, op, cin, cout, size, n, prec):
         close(gb, gb_ref, rtol=max(5e-5, tol), what="bgrad")
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("op,cin,cout,size,n", [
+    (pk.CONV3_S1, 16, 16, (64, 64, 64), 2),      # conv16s (sliding window), interior + edge tiles
+    (pk.CONV3_S1, 8, 16, (34, 38, 50), 1),       # conv16s with partial tiles in H and W, Cin < 16
+    (pk.CONV3_S1, 32, 32, (12, 12, 16), 2),      # generic kernel, fast epilogue
+    (pk.CONV3_S1, 48, 16, (9, 10, 20), 1),       # generic kernel, partial tiles (slow epilogue)
+    (pk.CONV3_S2, 16, 32, (16, 16, 32), 1),      # stride-2 data gradient (8 output-parity classes)
+    (pk.CONV1, 32, 16, (8, 8, 32), 2),
+    (pk.CONVT2, 16, 16, (6, 8, 16), 1),
+])
+def test_fused_norm_backward_sums(hip, op, cin, cout, size, n, prec):
+    """conv(..., nb=(x, scale, shift, slope)): the data-gradient epilogue accumulates the InstanceNorm-backward sums S1, S2 that
+    cwf_in_bwd_stats computes in a separate pass; dx from in_bwd_apply must match the two-pass in_bwd (same split-bf16 dgrad)."""
+    from cwf import functional as CF
+    d, h, w_ = size
+    x = rnd(n, d, h, w_, cin, seed=11)
+    wshape = (cin, cout, 2, 2, 2) if op == pk.CONVT2 else ((cout, cin, 1, 1, 1) if op == pk.CONV1 else (cout, cin, 3, 3, 3))
+    w = rnd(*wshape, seed=12, scale=1.0 / math.sqrt(cin * (27 if wshape[2] == 3 else 1)))
+    in_scale = rnd(n, cin, seed=14).abs() + 0.5
+    in_shift = rnd(n, cin, seed=15)
+    spec = _packed(CF.ConvSpec(op, cin, cout), w, prec)
+    do, ho, wo = pk.out_dims(op, d, h, w_)
+    dy = torch.zeros(n, do, ho, wo, spec.cout_alloc)
+    dy[..., :cout] = rnd(n, do, ho, wo, cout, seed=18)
+    xd, dyd, sc, sh = x.to(DEV), dy.to(DEV), in_scale.to(DEV), in_shift.to(DEV)
+    g1 = hip.conv(pk.dgrad_op(op), dyd, spec.wpk16_d, None, cin, out=torch.empty((n, d, h, w_, cin), device=DEV), prec=prec)
+    dx_two_pass = hip.in_bwd(g1, xd, sc, sh, 0.01)
+    sums = hip.new_stats(n, cin, DEV)
+    g2 = hip.conv(pk.dgrad_op(op), dyd, spec.wpk16_d, None, cin, out=torch.empty((n, d, h, w_, cin), device=DEV), prec=prec,
+                  stats=sums, nb=(xd, sc, sh, 0.01))
+    assert torch.equal(g1, g2)
+    dx_fused = hip.in_bwd_apply(g2, xd, sc, sh, 0.01, sums)
+    close(dx_fused, dx_two_pass.cpu(), rtol=2e-5, what="fused norm backward")
+
+
 def test_gather_batched_matches_index_maps(hip):
     from cwf import functional as CF
     packer = CF.WeightPacker()
