@@ -1,18 +1,18 @@
+"""Run-to-run gradient differences with the weight gradients on the main stream vs on the side stream (diagnostic)."""
 import os, sys
 sys.path.insert(0, ""+os.path.dirname(os.path.dirname(os.path.abspath(__file__)))+"/decouple-and-couple_learning_in_multi-modal_brain_tumor_segmentation_amd"); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cwf import kernels
 from cwf.trainer import Trainer
 from models.clswiseformer.cls_wise_former import get_cls_wise_former
-from oracle import reference_model as rm
 from utils import synthetic as syn
 DEV = "cuda:0"
 kernels.set_precision("bf16x3")
 x, target, edge = syn.synthetic_batch([0], (64, 64, 64))
 x, target, edge = x.to(DEV), target.to(DEV), edge.to(DEV)
 def run(flag):
+    torch.manual_seed(7)                                 # same random init for every run
     m = get_cls_wise_former(dataset="brats", _conv_repr=True, _pe_type="fixed").to(DEV)
-    m.load_state_dict(syn.det_state_dict(rm.param_shapes()), strict=False)
     m.train(); m.Unet_list.InitConv.dropout = 0.0
     for mod in m.modules():
         if hasattr(mod, "dropout_rate"): mod.dropout_rate = 0.0
