@@ -10,6 +10,7 @@
 // Packed weights: [class][ci_chunk16][tap pair][co_tile16][lane64][hi 8 | lo 8] bf16 (cwf_gather_split_bf16).
 // Geometry, tiling, epilogue (bias / residual / out_scale / InstanceNorm statistics) are those of conv_mfma.hip.
 #include "common.h"
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -168,14 +169,30 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
     // packed weights: block = 64 lanes x (hi 16 B | lo 16 B) = 128 uint4
     const uint4* wchunk = a.wpk + ((int64_t)g.cls_wbase16[cls] + (int64_t)chunk * nsteps * g.ntiles) * 128 + lane * 2;
     uint4 bh[PD][NT], bl[PD][NT];
+    // unconditional loads (indices clamped into the packed buffer: a partial channel group or a step past the end re-reads
+    // valid data that is never used) -- a branch around a global load makes the compiler give up counted s_waitcnt vmcnt(N),
+    // and a vmcnt(0) per tap pair costs one full L2 round trip per step (measured: ~1000 cycles per 96-cycle step at 16^3)
+    // (MT == 1, the deep small-step configurations; the large-tile configurations keep the guarded form: the straight-line
+    // one costs them an occupancy step -- 32 ch @ 64^3: 111 -> 132 us)
     auto load_b = [&](int s_, int slot) {
+      if (MT == 1) {
+        const int sc_ = min(s_, nsteps - 1);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        bh[slot][j] = make_uint4(0, 0, 0, 0); bl[slot][j] = make_uint4(0, 0, 0, 0);
-        if (nt0 + j < g.ntiles && s_ < nsteps) {
-          const uint4* p = wchunk + ((int64_t)s_ * g.ntiles + nt0 + j) * 128;
+        for (int j = 0; j < NT; ++j) {
+          const int jt = min(nt0 + j, g.ntiles - 1);
+          const uint4* p = wchunk + ((int64_t)sc_ * g.ntiles + jt) * 128;
           bh[slot][j] = p[0];
           if (X3) bl[slot][j] = p[1];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          bh[slot][j] = make_uint4(0, 0, 0, 0); bl[slot][j] = make_uint4(0, 0, 0, 0);
+          if (nt0 + j < g.ntiles && s_ < nsteps) {
+            const uint4* p = wchunk + ((int64_t)s_ * g.ntiles + nt0 + j) * 128;
+            bh[slot][j] = p[0];
+            if (X3) bl[slot][j] = p[1];
+          }
         }
       }
     };
@@ -184,36 +201,41 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
     if (chunk) __syncthreads();
     stage_tile_bf16<X3>(xh, xl, g, a.x, a.in_scale, a.in_shift, a.in_slope, n, chunk, ss, tid);
     __syncthreads();
-#pragma unroll 1
-    for (int s0 = 0; s0 < nsteps; s0 += PD) {
+    auto step = [&](int s, int d, bool refill) {          // tap pair s with ring slot d
+      const int t0 = tapofs[2 * s];
+      const int t1 = tapofs[(2 * s + 1 < ntaps) ? 2 * s + 1 : 2 * s];     // padded tap: weights are zero, address stays valid
+      const int to = (second ? t1 : t0) * 16;
+      uint4 ah[MT], al[MT];
 #pragma unroll
-      for (int d = 0; d < PD; ++d) {
-        const int s = s0 + d;
-        if (s < nsteps) {                                  // workgroup-uniform
-          const int t0 = tapofs[2 * s];
-          const int t1 = tapofs[(2 * s + 1 < ntaps) ? 2 * s + 1 : 2 * s];     // padded tap: weights are zero, address stays valid
-          const int to = (second ? t1 : t0) * 16;
-          uint4 ah[MT], al[MT];
+      for (int m = 0; m < MT; ++m) {
+        ah[m] = *reinterpret_cast<const uint4*>(xh + abase[m] + to);
+        if (X3) al[m] = *reinterpret_cast<const uint4*>(xl + abase[m] + to);
+      }
+      uint4 ch[NT], cl[NT];
 #pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            ah[m] = *reinterpret_cast<const uint4*>(xh + abase[m] + to);
-            if (X3) al[m] = *reinterpret_cast<const uint4*>(xl + abase[m] + to);
+      for (int j = 0; j < NT; ++j) { ch[j] = bh[d][j]; cl[j] = bl[d][j]; }
+      if (refill) load_b(s + PD, d);                       // refill this ring slot
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, ch[j]), acc[m][j], 0, 0, 0);
+          if (X3) {
+            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, cl[j]), acc[m][j], 0, 0, 0);
+            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[m]), __builtin_bit_cast(bf16x8, ch[j]), acc[m][j], 0, 0, 0);
           }
-          uint4 ch[NT], cl[NT];
-#pragma unroll
-          for (int j = 0; j < NT; ++j) { ch[j] = bh[d][j]; cl[j] = bl[d][j]; }
-          load_b(s + PD, d);                               // refill this ring slot (no-op past the last step)
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-              acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, ch[j]), acc[m][j], 0, 0, 0);
-              if (X3) {
-                acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, cl[j]), acc[m][j], 0, 0, 0);
-                acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[m]), __builtin_bit_cast(bf16x8, ch[j]), acc[m][j], 0, 0, 0);
-              }
-            }
         }
+    };
+    if (MT == 1 && nsteps == 14) {
+      // 27-tap operators (all 3x3x3 forward / stride-1 data-gradient launches): straight-line, refills known at compile time
+#pragma unroll
+      for (int s = 0; s < 14; ++s) step(s, s % PD, s + PD < 14);
+    } else {
+#pragma unroll 1
+      for (int s0 = 0; s0 < nsteps; s0 += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d)
+          if (s0 + d < nsteps) step(s0 + d, d, true);       // workgroup-uniform
       }
     }
   }
@@ -1376,7 +1398,12 @@ extern "C" int cwf_conv_mfma_bf16_nb(int op, int x3, const float* x, int x_ldc, 
   int cd[3] = {Do, Ho, Wo}; int ncls = 1;
   if (op == CWF_CONVT2) { cd[0] = Di; cd[1] = Hi; cd[2] = Wi; ncls = 8; }
   if (op == CWF_CONV3_S2_DGRAD) { cd[0] = (Do + 1) / 2; cd[1] = (Ho + 1) / 2; cd[2] = (Wo + 1) / 2; ncls = 8; }
-  const TileCfg c = choose_cfg(op, cd, ncls, N, cdiv(Cout, 16));
+  TileCfg c = choose_cfg(op, cd, ncls, N, cdiv(Cout, 16));
+  {                                                    // tuning aid: CWF_FORCE_CFG="MT,NT,WM" overrides the tile choice
+    static const char* force = getenv("CWF_FORCE_CFG");
+    int fm, fn, fw;
+    if (force && sscanf(force, "%d,%d,%d", &fm, &fn, &fw) == 3) { c.MT = fm; c.NT = fn; c.WM = fw; }
+  }
   int rc = cwf_build_geom(a.g, op, N, Di, Hi, Wi, Cin, x_ldc, Do, Ho, Wo, Cout, y_ldc, c.MT * c.WM);
   if (rc) return rc;
   a.x = x; a.wpk = reinterpret_cast<const uint4*>(wpk16); a.bias = bias; a.y = y; a.in_scale = in_scale; a.in_shift = in_shift;
