@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       dx[(int64_t)row * E + c] = o;
     }
   }
+  if (!dgamma) return;                                 // parameter gradients come from layernorm_bwd_params_kernel (uniform)
 #pragma unroll
   for (int i = 0; i < PER; ++i) { sg[(w * PER + i) * 64 + lane] = pg[i]; sb[(w * PER + i) * 64 + lane] = pb[i]; }
   __syncthreads();
@@ -210,9 +211,37 @@ extern "C" int cwf_layernorm_fwd(const float* x, const float* gamma, const float
   return 0;
 }
 
+// dgamma[c] = sum_rows dy*xhat, dbeta[c] = sum_rows dy: one block per 64 columns, rows split over the 4 waves, fixed summation
+// order (deterministic), plain stores -- no zero-initialised buffers and no float atomics (the token path is launch-bound:
+// this removes two fill launches per LayerNorm backward).
+__global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int E) {
+  __shared__ float sg[4][64], sb[4][64];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 64 + lane;
+  float ag = 0.f, ab = 0.f;
+  if (c < E) {
+    for (int row = w; row < rows; row += 4) {
+      const float d = dy[(int64_t)row * E + c];
+      ag += d * (x[(int64_t)row * E + c] - mean[row]) * rstd[row];
+      ab += d;
+    }
+  }
+  sg[w][lane] = ag; sb[w][lane] = ab;
+  __syncthreads();
+  if (w == 0 && c < E) {
+    dgamma[c] = (sg[0][lane] + sg[1][lane]) + (sg[2][lane] + sg[3][lane]);
+    dbeta[c] = (sb[0][lane] + sb[1][lane]) + (sb[2][lane] + sb[3][lane]);
+  }
+}
+
 extern "C" int cwf_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                  float* dx, float* dgamma, float* dbeta, int rows, int E, int accumulate, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0) return CWF_E_BADARG;
+  if (E != 512 && E != 256 && E != 128 && E != 64) return CWF_E_BADARG;
+  hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3(cdiv(E, 64)), dim3(256), 0, cwf_stream(stream), dy, x, mean, rstd, dgamma, dbeta, rows, E);
+  dgamma = nullptr; dbeta = nullptr;                   // the row kernel below computes dx only
   dim3 grid(cdiv(rows, 4));
   if (E == 512) hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, dim3(256), 0, cwf_stream(stream), dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, E, accumulate);
   else if (E == 256) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, dim3(256), 0, cwf_stream(stream), dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, E, accumulate);

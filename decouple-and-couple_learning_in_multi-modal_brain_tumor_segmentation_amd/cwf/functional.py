@@ -299,8 +299,8 @@ class _LayerNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
-        dg = torch.zeros_like(gamma)
-        db = torch.zeros_like(gamma)
+        dg = torch.empty_like(gamma)         # written, not accumulated (cwf_layernorm_bwd)
+        db = torch.empty_like(gamma)
         dx = backend().layernorm_bwd(dy, x.contiguous(), gamma, mean, rstd, dg, db)
         return dx, dg, db
 

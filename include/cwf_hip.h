@@ -154,7 +154,7 @@ int cwf_gemm(const float* A, int64_t sa_m, int64_t sa_k, int64_t sa_zb, int64_t 
 /* rows x E LayerNorm (eps 1e-5): y = (x-mean)*rstd*gamma+beta; saves mean/rstd [rows] */
 int cwf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                       int rows, int E, float eps, void* stream);
-/* dx (+= if accumulate), dgamma/dbeta += (atomic) -- caller zeroes dgamma/dbeta */
+/* dx (+= if accumulate); dgamma/dbeta are WRITTEN (deterministic column reduction, no zero-initialisation needed) */
 int cwf_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                       float* dx, float* dgamma, float* dbeta, int rows, int E, int accumulate, void* stream);
 /* in-place row softmax over `cols` (rows are contiguous, stride ld) and its backward dS = P*(dP - sum(dP*P)) */

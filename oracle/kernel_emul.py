@@ -170,8 +170,8 @@ class EmulBackend:
         d = dy.reshape(-1, e)
         g = d * gamma
         dx = rstd[:, None] * (g - g.mean(-1, keepdim=True) - xh * (g * xh).mean(-1, keepdim=True))
-        dgamma += (d * xh).sum(0)
-        dbeta += d.sum(0)
+        dgamma.copy_((d * xh).sum(0))        # written, not accumulated (matches cwf_layernorm_bwd)
+        dbeta.copy_(d.sum(0))
         return dx.reshape(x.shape)
 
     def softmax_rows_(self, s):
