@@ -32,6 +32,27 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Counter-based uniform in [0,1): splitmix64 of (seed, element counter).  Dropout masks are never materialised: every kernel
+// that applies one recomputes keep(ctr) from the element's index, forward and backward alike.
+__device__ __forceinline__ float cwf_u01(uint64_t seed, uint64_t ctr) {
+  uint64_t z = (seed ^ 0x9E3779B97F4A7C15ull) + ctr * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+// Device-resident generator state {seed, step}.  `step` is advanced by a KERNEL (cwf_rng_advance) once per training step, so it
+// also advances on every replay of a captured hipGraph; per-site counters offsets are static within a step.
+__device__ __forceinline__ float cwf_rng_u01(const uint64_t* __restrict__ rng, uint64_t ctr) {
+  return cwf_u01(rng[0] + rng[1] * 0xD6E8FEB86659FD93ull, ctr);
+}
+// pre-scaled keep factor of one (p) or two chained (p, p2) dropouts of the same tensor of n elements
+__device__ __forceinline__ float cwf_keep(const uint64_t* __restrict__ rng, uint64_t off, uint64_t i, uint64_t n, float p, float p2) {
+  float v = cwf_rng_u01(rng, off + i) >= p ? 1.0f / (1.0f - p) : 0.f;
+  if (p2 > 0.f) v *= cwf_rng_u01(rng, off + n + i) >= p2 ? 1.0f / (1.0f - p2) : 0.f;
+  return v;
+}
+
 // hardware f64 / f32 atomic add (no CAS loop)
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }

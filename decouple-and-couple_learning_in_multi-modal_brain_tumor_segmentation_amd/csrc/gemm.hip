@@ -5,13 +5,7 @@
 // kernels are kept simple (64x64 or 32x32 workgroup tiles, K steps of 32, one pass).
 #include "common.h"
 
-struct GemmArgs {
-  const float* A; int64_t sa_m, sa_k, sa_zb, sa_zh;
-  const float* B; int64_t sb_k, sb_n, sb_zb, sb_zh;
-  float* C; int64_t sc_m, sc_zb, sc_zh;
-  const float* bias; const float* residual; int64_t sr_m, sr_zb, sr_zh;
-  int M, N, K, ZH; float alpha; int act; int accumulate;
-};
+typedef struct cwf_gemm_args GemmArgs;
 
 #define GK 32
 
@@ -20,6 +14,14 @@ struct GemmArgs {
 // pipelining).  These GEMMs are tiny (M = 129..516 rows): with 64 x 64 tiles most of them launch 24-48 workgroups on a
 // 256-CU chip and each workgroup grinds through its K loop alone at the fp32 MFMA rate, so small problems use 32 x 32 tiles
 // (4x the workgroups, a quarter of the per-step MFMA time).
+// Fusions that keep the token path at a handful of launches (see cwf_hip.h: struct cwf_gemm_args):
+//   * operand switch at a tile boundary (A2/split_n, B2/split_m): q = LN1(x) Wq^T and kv = LN2(x2) Wkv^T are ONE launch
+//     over the reference's [1536, 512] qkv weight; so is its weight gradient [dq^T a ; dkv^T b];
+//   * dropout of the A operand recomputed from the element index (the backward of y = x + drop(o Wo^T + b) reads dy once per
+//     GEMM and never materialises dy * mask), dropout in the epilogue (forward of the same);
+//   * rowsum of the (dropped) A operand from the workgroups of the first column tile = the bias gradient of a Linear,
+//     computed by one extra MFMA against a ones vector;
+//   * C2: the pre-activation next to the GELU output (saved for backward instead of being recomputed by a second GEMM).
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs a) {
   constexpr int LDA_S = GK + 1, LDB_S = TN + 16;
@@ -31,15 +33,20 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs a) {
   const int wr = wave >> 1, wc = wave & 1;
   const int r = lane & 15, kq = lane >> 4;
   const int zb = blockIdx.z / a.ZH, zh = blockIdx.z % a.ZH;
-  const float* A = a.A + zb * a.sa_zb + zh * a.sa_zh;
-  const float* B = a.B + zb * a.sb_zb + zh * a.sb_zh;
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+  const int64_t a_zoff = zb * a.sa_zb + zh * a.sa_zh;
+  const float* A = ((a.A2 && n0 >= a.split_n) ? a.A2 : a.A) + a_zoff;
+  const float* B = ((a.B2 && m0 >= a.split_m) ? a.B2 : a.B) + zb * a.sb_zb + zh * a.sb_zh;
+  const bool a_drop = a.a_drop_p > 0.f;
+  const bool do_rs = a.rowsum != nullptr && blockIdx.x == 0 && wc == 0;
 
-  f32x4 acc[IM][JN];
+  f32x4 acc[IM][JN], accr[IM];
 #pragma unroll
-  for (int i = 0; i < IM; ++i)
+  for (int i = 0; i < IM; ++i) {
+    accr[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < JN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 
   const bool a_kfast = (a.sa_k == 1);
   const bool b_nfast = (a.sb_n == 1);
@@ -58,7 +65,13 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < SA; ++i) {
       const int gm = m0 + am[i], gk = k0 + ak[i];
-      ra[i] = (gm < a.M && gk < a.K) ? A[gm * a.sa_m + gk * a.sa_k] : 0.f;
+      float v = 0.f;
+      if (gm < a.M && gk < a.K) {
+        const int64_t off = gm * a.sa_m + gk * a.sa_k;
+        v = A[off];
+        if (a_drop) v *= cwf_keep(a.rng, a.a_drop_off, (uint64_t)(a_zoff + off), a.a_drop_n, a.a_drop_p, a.a_drop_p2);
+      }
+      ra[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < SB; ++i) {
@@ -86,10 +99,17 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs a) {
       for (int i = 0; i < IM; ++i)
 #pragma unroll
         for (int j = 0; j < JN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+      if (do_rs) {
+#pragma unroll
+        for (int i = 0; i < IM; ++i) accr[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], 1.0f, accr[i], 0, 0, 0);
+      }
     }
   }
-  float* C = a.C + zb * a.sc_zb + zh * a.sc_zh;
+  const int64_t c_zoff = zb * a.sc_zb + zh * a.sc_zh;
+  float* C = a.C + c_zoff;
+  float* C2 = a.C2 ? a.C2 + c_zoff : nullptr;
   const float* R = a.residual ? a.residual + zb * a.sr_zb + zh * a.sr_zh : nullptr;
+  const bool c_drop = a.c_drop_p > 0.f;
 #pragma unroll
   for (int i = 0; i < IM; ++i)
 #pragma unroll
@@ -101,14 +121,46 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs a) {
       for (int e = 0; e < 4; ++e) {
         const int gm = m0 + wr * (TM / 2) + i * 16 + kq * 4 + e;
         if (gm >= a.M) continue;
+        const int64_t off = gm * a.sc_m + gn;
         float v = acc[i][j][e] * a.alpha + bv;
+        if (C2) C2[off] = v;
         if (a.act == 1) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        if (c_drop) v *= cwf_keep(a.rng, a.c_drop_off, (uint64_t)(c_zoff + off), a.c_drop_n, a.c_drop_p, a.c_drop_p2);
         if (R) v += R[gm * a.sr_m + gn];
-        float* p = C + gm * a.sc_m + gn;
+        float* p = C + off;
         if (a.accumulate) v += *p;
         *p = v;
       }
     }
+  if (do_rs && r == 0) {                        // every column of accr holds the row sum; column 0 writes it
+#pragma unroll
+    for (int i = 0; i < IM; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int gm = m0 + wr * (TM / 2) + i * 16 + kq * 4 + e;
+        if (gm < a.M) a.rowsum[gm] = (a.rowsum_acc ? a.rowsum[gm] : 0.f) + accr[i][e];
+      }
+  }
+}
+
+extern "C" int cwf_gemm_ex(const struct cwf_gemm_args* args, void* stream) {
+  if (!args) return CWF_E_BADARG;
+  const GemmArgs& a = *args;
+  if (!a.A || !a.B || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0 || a.ZB <= 0 || a.ZH <= 0) return CWF_E_BADARG;
+  if ((int64_t)a.ZB * a.ZH > 65535) return CWF_E_TOOLARGE;
+  if ((a.A2 && (a.split_n & 63)) || (a.B2 && (a.split_m & 63))) return CWF_E_BADARG;          // operand switch on a tile boundary
+  if ((a.a_drop_p > 0.f || a.c_drop_p > 0.f) && !a.rng) return CWF_E_BADARG;
+  if (a.rowsum && (int64_t)a.ZB * a.ZH != 1) return CWF_E_BADARG;
+  const int64_t wg64 = (int64_t)cdiv(a.N, 64) * cdiv(a.M, 64) * a.ZB * a.ZH;
+  if (wg64 >= 256) {
+    dim3 grid(cdiv(a.N, 64), cdiv(a.M, 64), a.ZB * a.ZH);
+    hipLaunchKernelGGL((gemm_mfma_kernel<64, 64>), grid, dim3(256), 0, cwf_stream(stream), a);
+  } else {
+    dim3 grid(cdiv(a.N, 32), cdiv(a.M, 32), a.ZB * a.ZH);
+    hipLaunchKernelGGL((gemm_mfma_kernel<32, 32>), grid, dim3(256), 0, cwf_stream(stream), a);
+  }
+  CWF_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int cwf_gemm(const float* A, int64_t sa_m, int64_t sa_k, int64_t sa_zb, int64_t sa_zh,
@@ -116,20 +168,13 @@ extern "C" int cwf_gemm(const float* A, int64_t sa_m, int64_t sa_k, int64_t sa_z
                         float* C, int64_t sc_m, int64_t sc_zb, int64_t sc_zh,
                         const float* bias, const float* residual, int64_t sr_m, int64_t sr_zb, int64_t sr_zh,
                         int M, int Nn, int K, int ZB, int ZH, float alpha, int act, int accumulate, void* stream) {
-  if (!A || !B || !C || M <= 0 || Nn <= 0 || K <= 0 || ZB <= 0 || ZH <= 0) return CWF_E_BADARG;
-  if ((int64_t)ZB * ZH > 65535) return CWF_E_TOOLARGE;
-  GemmArgs a{A, sa_m, sa_k, sa_zb, sa_zh, B, sb_k, sb_n, sb_zb, sb_zh, C, sc_m, sc_zb, sc_zh,
-             bias, residual, sr_m, sr_zb, sr_zh, M, Nn, K, ZH, alpha, act, accumulate};
-  const int64_t wg64 = (int64_t)cdiv(Nn, 64) * cdiv(M, 64) * ZB * ZH;
-  if (wg64 >= 256) {
-    dim3 grid(cdiv(Nn, 64), cdiv(M, 64), ZB * ZH);
-    hipLaunchKernelGGL((gemm_mfma_kernel<64, 64>), grid, dim3(256), 0, cwf_stream(stream), a);
-  } else {
-    dim3 grid(cdiv(Nn, 32), cdiv(M, 32), ZB * ZH);
-    hipLaunchKernelGGL((gemm_mfma_kernel<32, 32>), grid, dim3(256), 0, cwf_stream(stream), a);
-  }
-  CWF_LAUNCH_CHECK();
-  return 0;
+  GemmArgs a = {};
+  a.A = A; a.sa_m = sa_m; a.sa_k = sa_k; a.sa_zb = sa_zb; a.sa_zh = sa_zh;
+  a.B = B; a.sb_k = sb_k; a.sb_n = sb_n; a.sb_zb = sb_zb; a.sb_zh = sb_zh;
+  a.C = C; a.sc_m = sc_m; a.sc_zb = sc_zb; a.sc_zh = sc_zh;
+  a.bias = bias; a.residual = residual; a.sr_m = sr_m; a.sr_zb = sr_zb; a.sr_zh = sr_zh;
+  a.M = M; a.N = Nn; a.K = K; a.ZB = ZB; a.ZH = ZH; a.alpha = alpha; a.act = act; a.accumulate = accumulate;
+  return cwf_gemm_ex(&a, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
@@ -325,6 +370,184 @@ extern "C" int cwf_gelu_bwd(const float* x, const float* dy, float* dx, int64_t 
 extern "C" int cwf_colsum(const float* x, int64_t rows, int cols, int ld, float* out, int accumulate, void* stream) {
   if (!x || !out || rows <= 0 || cols <= 0) return CWF_E_BADARG;
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, cwf_stream(stream), x, rows, cols, ld, out, accumulate);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ paired LayerNorm
+// The couplers' blocks always normalise TWO operands (PreNormDrop: norm(x), norm2(x2), ResidualNorm.py:23-32), and the four
+// cross-attentions of a region run as two batches of sequence PAIRS [B][2][T][E] (ClsWiseTransformer.py:44-50: the second
+// batch attends a <-> b, i.e. x2 is x with the two halves of every pair swapped).  `perm_T` > 0 expresses that swap: row r
+// of the second problem reads x2[perm(r)], perm(r) = r with bit 0 of (r / perm_T) flipped.  One wave per (problem, row).
+__device__ __forceinline__ int ln_perm(int r, int perm_T) { return perm_T > 0 ? (((r / perm_T) ^ 1) * perm_T + r % perm_T) : r; }
+
+template <int PER>
+__global__ __launch_bounds__(256) void ln_pair_fwd_kernel(const float* __restrict__ x, const float* __restrict__ x2, int perm_T,
+                                                         const float* __restrict__ g1, const float* __restrict__ b1,
+                                                         const float* __restrict__ g2, const float* __restrict__ b2,
+                                                         float* __restrict__ ya, float* __restrict__ yb, float* __restrict__ stats,
+                                                         int rows, int E, float eps) {
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int prob = wid / rows, row = wid % rows;
+  if (prob >= (x2 ? 2 : 1)) return;
+  const float* xr = prob ? x2 + (int64_t)ln_perm(row, perm_T) * E : x + (int64_t)row * E;
+  const float* gamma = prob ? g2 : g1; const float* beta = prob ? b2 : b1;
+  float* y = (prob ? yb : ya) + (int64_t)row * E;
+  float v[PER]; float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { v[i] = xr[lane + 64 * i]; s += v[i]; }
+  const float mu = wave_sum(s) / (float)E;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { const float d = v[i] - mu; q += d * d; }
+  const float rs = rsqrtf(wave_sum(q) / (float)E + eps);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { const int c = lane + 64 * i; y[c] = (v[i] - mu) * rs * gamma[c] + beta[c]; }
+  if (lane == 0) { stats[((int64_t)prob * rows + row) * 2] = mu; stats[((int64_t)prob * rows + row) * 2 + 1] = rs; }
+}
+
+// per-lane LayerNorm input gradient of one row: o[i] += rstd * (g - mean(g) - xhat * mean(g * xhat)), g = d * gamma
+template <int PER>
+__device__ __forceinline__ void ln_bwd_row(float* o, const float* __restrict__ d, const float* v, const float* __restrict__ gamma,
+                                           float mu, float rs, int lane, int E) {
+  float g[PER], h[PER]; float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = lane + 64 * i;
+    h[i] = (v[i] - mu) * rs; g[i] = d[c] * gamma[c];
+    s1 += g[i]; s2 += g[i] * h[i];
+  }
+  s1 = wave_sum(s1) / (float)E; s2 = wave_sum(s2) / (float)E;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) o[i] += rs * (g[i] - s1 - h[i] * s2);
+}
+
+// dual (dx2 != NULL):  dx[r] = dy[r] + LN1'(da[r]; x[r]) ;  dx2[r] = LN2'(db[r]; x2[r])                (perm_T must be 0)
+// self (dx2 == NULL, db != NULL; x2 == x up to perm):  dx[r] = dy[r] + LN1'(da[r]; x[r]) + LN2'(db[perm(r)]; x[r])
+// single (db == NULL):  dx[r] = dy[r] + LN1'(da[r]; x[r])
+template <int PER>
+__global__ __launch_bounds__(256) void ln_pair_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ da, const float* __restrict__ db,
+                                                         const float* __restrict__ x, const float* __restrict__ x2, int perm_T,
+                                                         const float* __restrict__ g1, const float* __restrict__ g2, const float* __restrict__ stats,
+                                                         float* __restrict__ dx, float* __restrict__ dx2, int rows, int E) {
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int prob = wid / rows, row = wid % rows;
+  if (prob >= (dx2 ? 2 : 1)) return;
+  float v[PER], o[PER];
+  const float* xr = (prob ? x2 : x) + (int64_t)row * E;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { v[i] = xr[lane + 64 * i]; o[i] = 0.f; }
+  if (prob == 0) {
+    if (dy) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) o[i] = dy[(int64_t)row * E + lane + 64 * i];
+    }
+    ln_bwd_row<PER>(o, da + (int64_t)row * E, v, g1, stats[(int64_t)row * 2], stats[(int64_t)row * 2 + 1], lane, E);
+    if (db && !dx2) {
+      const int pr = ln_perm(row, perm_T);
+      ln_bwd_row<PER>(o, db + (int64_t)pr * E, v, g2, stats[((int64_t)rows + pr) * 2], stats[((int64_t)rows + pr) * 2 + 1], lane, E);
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) dx[(int64_t)row * E + lane + 64 * i] = o[i];
+  } else {
+    ln_bwd_row<PER>(o, db + (int64_t)row * E, v, g2, stats[((int64_t)rows + row) * 2], stats[((int64_t)rows + row) * 2 + 1], lane, E);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) dx2[(int64_t)row * E + lane + 64 * i] = o[i];
+  }
+}
+
+// dgamma_p[c] (+)= sum_rows d_p * xhat_p, dbeta_p[c] (+)= sum_rows d_p for p = 1 (da, x) and p = 2 (db, x2[perm]); grid (E/64, 1 or 2),
+// 1024 threads = 64 columns x 16 row lanes, four rows in flight per lane (the reduction is a chain of dependent HBM/L2 round
+// trips: at 4 row lanes and one row in flight it took 30 us for 129 rows); fixed summation order, plain stores (accumulate = the
+// weight-sharing sum over the uses of one LayerNorm, ClsWiseTransformer.py:44-50)
+__global__ __launch_bounds__(1024) void ln_pair_params_kernel(const float* __restrict__ da, const float* __restrict__ db,
+                                                             const float* __restrict__ x, const float* __restrict__ x2, int perm_T,
+                                                             const float* __restrict__ stats, float* __restrict__ dg1, float* __restrict__ db1,
+                                                             float* __restrict__ dg2, float* __restrict__ db2, int rows, int E, int accumulate) {
+  __shared__ float sg[16][64], sb[16][64];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, prob = blockIdx.y;
+  const int c = blockIdx.x * 64 + lane;
+  const float* d = prob ? db : da; const float* xs = prob ? x2 : x;
+  const float* st = stats + (int64_t)prob * rows * 2;
+  float ag = 0.f, ab = 0.f;
+  if (c < E) {
+    for (int row0 = w; row0 < rows; row0 += 64) {
+      float dv[4], xv[4], mu[4], rs[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = row0 + 16 * u;
+        const bool ok = row < rows;
+        const int xr = ok ? (prob ? ln_perm(row, perm_T) : row) : 0;
+        dv[u] = ok ? d[(int64_t)row * E + c] : 0.f;
+        xv[u] = ok ? xs[(int64_t)xr * E + c] : 0.f;
+        mu[u] = ok ? st[row * 2] : 0.f; rs[u] = ok ? st[row * 2 + 1] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { ag += dv[u] * (xv[u] - mu[u]) * rs[u]; ab += dv[u]; }
+    }
+  }
+  sg[w][lane] = ag; sb[w][lane] = ab;
+  __syncthreads();
+  if (w == 0 && c < E) {
+    float tg = 0.f, tb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { tg += sg[i][lane]; tb += sb[i][lane]; }
+    float* og = prob ? dg2 : dg1; float* ob = prob ? db2 : db1;
+    og[c] = accumulate ? og[c] + tg : tg;
+    ob[c] = accumulate ? ob[c] + tb : tb;
+  }
+}
+
+#define LN_DISPATCH(KERNEL, grid, ...)                                                                                       \
+  do {                                                                                                                       \
+    if (E == 512) hipLaunchKernelGGL(KERNEL<8>, grid, dim3(256), 0, cwf_stream(stream), __VA_ARGS__);                        \
+    else if (E == 256) hipLaunchKernelGGL(KERNEL<4>, grid, dim3(256), 0, cwf_stream(stream), __VA_ARGS__);                   \
+    else if (E == 128) hipLaunchKernelGGL(KERNEL<2>, grid, dim3(256), 0, cwf_stream(stream), __VA_ARGS__);                   \
+    else if (E == 64) hipLaunchKernelGGL(KERNEL<1>, grid, dim3(256), 0, cwf_stream(stream), __VA_ARGS__);                    \
+    else return CWF_E_BADARG;                                                                                                \
+  } while (0)
+
+extern "C" int cwf_ln_pair_fwd(const float* x, const float* x2, int perm_T, const float* g1, const float* b1, const float* g2, const float* b2,
+                               float* ya, float* yb, float* stats, int rows, int E, float eps, void* stream) {
+  if (!x || !g1 || !b1 || !ya || !stats || rows <= 0 || (x2 && (!g2 || !b2 || !yb))) return CWF_E_BADARG;
+  if (perm_T > 0 && rows % (2 * perm_T)) return CWF_E_BADARG;
+  dim3 grid(cdiv(rows * (x2 ? 2 : 1), 4));
+  LN_DISPATCH(ln_pair_fwd_kernel, grid, x, x2, perm_T, g1, b1, g2, b2, ya, yb, stats, rows, E, eps);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cwf_ln_pair_bwd(const float* dy, const float* da, const float* db, const float* x, const float* x2, int perm_T,
+                               const float* g1, const float* g2, const float* stats, float* dx, float* dx2,
+                               float* dg1, float* db1, float* dg2, float* db2, int rows, int E, int accumulate_params, void* stream) {
+  if (!da || !x || !g1 || !stats || !dx || !dg1 || !db1 || rows <= 0) return CWF_E_BADARG;
+  if (db && (!x2 || !g2 || !dg2 || !db2)) return CWF_E_BADARG;
+  if (dx2 && (!db || perm_T != 0)) return CWF_E_BADARG;
+  if (perm_T > 0 && rows % (2 * perm_T)) return CWF_E_BADARG;
+  if (E != 512 && E != 256 && E != 128 && E != 64) return CWF_E_BADARG;
+  hipLaunchKernelGGL(ln_pair_params_kernel, dim3(cdiv(E, 64), db ? 2 : 1), dim3(1024), 0, cwf_stream(stream), da, db, x, x2, perm_T, stats,
+                     dg1, db1, dg2, db2, rows, E, accumulate_params);
+  dim3 grid(cdiv(rows * (dx2 ? 2 : 1), 4));
+  LN_DISPATCH(ln_pair_bwd_kernel, grid, dy, da, db, x, x2, perm_T, g1, g2, stats, dx, dx2, rows, E);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+
+// dz = dh * keep(i) * gelu'(z): the backward of Dropout(GELU(z)) (FeedForward, ResidualNorm.py:40-43) with the mask recomputed
+__global__ void gelu_bwd_drop_kernel(const float* __restrict__ z, const float* __restrict__ dh, float* __restrict__ dz, int64_t n,
+                                     const uint64_t* __restrict__ rng, uint64_t off, float p) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = z[i];
+  const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+  float g = dh[i] * (cdf + v * pdf);
+  if (p > 0.f) g *= cwf_keep(rng, off, (uint64_t)i, (uint64_t)n, p, 0.f);
+  dz[i] = g;
+}
+extern "C" int cwf_gelu_bwd_drop(const float* z, const float* dh, float* dz, int64_t n, const uint64_t* rng, uint64_t off, float p, void* stream) {
+  if (!z || !dh || !dz || n <= 0 || (p > 0.f && !rng) || p < 0.f || p >= 1.f) return CWF_E_BADARG;
+  hipLaunchKernelGGL(gelu_bwd_drop_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, cwf_stream(stream), z, dh, dz, n, rng, off, p);
   CWF_LAUNCH_CHECK();
   return 0;
 }

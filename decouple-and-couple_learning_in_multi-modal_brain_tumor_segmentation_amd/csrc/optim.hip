@@ -79,13 +79,6 @@ __global__ void copy_strided_kernel(const float* __restrict__ x, int x_ldc, floa
 // ResidualNorm.py:25-31,40-45): mask[i] = keep_i / (1 - p), keep_i ~ Bernoulli(1 - p) from a counter-based generator
 // (splitmix64 of seed and element counter -- reproducible for a given torch seed and call order, no generator state on the
 // device).  p2 > 0 multiplies a second, independent mask in (two dropouts acting in sequence on one tensor).
-__device__ __forceinline__ float cwf_u01(uint64_t seed, uint64_t ctr) {
-  uint64_t z = (seed ^ 0x9E3779B97F4A7C15ull) + ctr * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
 __global__ void dropout_mask_kernel(float* __restrict__ m, int64_t n, float p, float p2, uint64_t seed, uint64_t offset) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -100,6 +93,27 @@ extern "C" int cwf_dropout_mask(float* mask, int64_t n, float p, float p2, uint6
   return 0;
 }
 
+// device-resident generator state {seed, step}: see common.h.  The advance is a kernel so that a captured training step draws
+// fresh masks on every replay; the keep-mask kernel below is what remains of materialised masks (the stem's dropout3d channel
+// scale, Unet_skipconnection.py:31).
+__global__ void rng_advance_kernel(uint64_t* rng) { if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += 1; }
+extern "C" int cwf_rng_advance(uint64_t* rng, void* stream) {
+  if (!rng) return CWF_E_BADARG;
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, cwf_stream(stream), rng);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+__global__ void dropout_mask_rng_kernel(float* __restrict__ m, int64_t n, float p, float p2, const uint64_t* __restrict__ rng, uint64_t off) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) m[i] = cwf_keep(rng, off, (uint64_t)i, (uint64_t)n, p, p2);
+}
+extern "C" int cwf_dropout_mask_rng(float* mask, int64_t n, float p, float p2, const uint64_t* rng, uint64_t offset, void* stream) {
+  if (!mask || !rng || n <= 0 || p < 0.f || p >= 1.f || p2 < 0.f || p2 >= 1.f) return CWF_E_BADARG;
+  hipLaunchKernelGGL(dropout_mask_rng_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, cwf_stream(stream), mask, n, p, p2, rng, offset);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int cwf_mul(const float* a, const float* b, float* y, int64_t n, void* stream) {
   if (!a || !b || !y || n <= 0) return CWF_E_BADARG;
   hipLaunchKernelGGL(mul_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, cwf_stream(stream), a, b, y, n);
@@ -109,6 +123,16 @@ extern "C" int cwf_mul(const float* a, const float* b, float* y, int64_t n, void
 extern "C" int cwf_add(const float* a, const float* b, float* y, int64_t n, void* stream) {
   if (!a || !b || !y || n <= 0) return CWF_E_BADARG;
   hipLaunchKernelGGL(add_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, cwf_stream(stream), a, b, y, n);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+__global__ void add3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, float* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = (a[i] + b[i]) + c[i];
+}
+extern "C" int cwf_add3(const float* a, const float* b, const float* c, float* y, int64_t n, void* stream) {
+  if (!a || !b || !c || !y || n <= 0) return CWF_E_BADARG;
+  hipLaunchKernelGGL(add3_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, cwf_stream(stream), a, b, c, y, n);
   CWF_LAUNCH_CHECK();
   return 0;
 }
@@ -127,5 +151,5 @@ extern "C" int cwf_copy_strided(const float* x, int x_ldc, float* y, int y_ldc, 
   return 0;
 }
 
-extern "C" int cwf_version(void) { return 1; }
+extern "C" int cwf_version(void) { return 2; }
 extern "C" const char* cwf_arch(void) { return "gfx950"; }

@@ -13,6 +13,7 @@ I = C.c_int
 L = C.c_int64
 F = C.c_float
 U = C.c_uint32
+U64 = C.c_uint64
 
 # name -> argtypes, exactly as declared in include/cwf_hip.h
 SIGNATURES = {
@@ -61,7 +62,42 @@ SIGNATURES = {
     "cwf_add": [P, P, P, L, P],
     "cwf_channel_scale": [P, I, P, P, I, I, L, I, P],
     "cwf_copy_strided": [P, I, P, I, L, I, P],
+    "cwf_add3": [P, P, P, P, L, P],
+    "cwf_gemm_ex": [P, P],
+    "cwf_attn_fwd": [P, L, P, L, I, I, I, I, F, P, U64, F, P],
+    "cwf_attn_bwd": [P, L, P, L, P, I, I, I, I, F, P, U64, F, P],
+    "cwf_ln_pair_fwd": [P, P, I, P, P, P, P, P, P, P, I, I, F, P],
+    "cwf_ln_pair_bwd": [P, P, P, P, P, I, P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "cwf_gelu_bwd_drop": [P, P, P, L, P, U64, F, P],
+    "cwf_token_scores2": [P, P, L, P, L, P, P, I, I, I, P],
+    "cwf_topk_inv": [P, P, P, P, P, P, I, I, I, P],
+    "cwf_index_inv": [P, P, I, I, I, P],
+    "cwf_gather_multi": [P, I, I, I, I, F, P, F, P],
+    "cwf_scatter_inv": [P, P, P, L, L, P, L, P, P, I, I, I, P],
+    "cwf_scatter_bwd": [P, P, P, P, P, P, L, L, P, L, P, L, P, L, L, P, L, I, I, I, I, P],
+    "cwf_token_grad": [P, P, P, L, P, P, P, L, P, L, P, U64, U64, F, P, I, I, I, I, P],
+    "cwf_head_grad": [P, P, P, P, L, P, P, I, I, P],
+    "cwf_rng_advance": [P, P],
+    "cwf_dropout_mask_rng": [P, L, F, F, P, U64, P],
 }
+
+
+class GemmArgs(C.Structure):
+    """struct cwf_gemm_args (include/cwf_hip.h)"""
+    _fields_ = [("A", P), ("sa_m", L), ("sa_k", L), ("sa_zb", L), ("sa_zh", L),
+                ("B", P), ("sb_k", L), ("sb_n", L), ("sb_zb", L), ("sb_zh", L),
+                ("C", P), ("sc_m", L), ("sc_zb", L), ("sc_zh", L),
+                ("bias", P), ("residual", P), ("sr_m", L), ("sr_zb", L), ("sr_zh", L),
+                ("M", I), ("N", I), ("K", I), ("ZB", I), ("ZH", I), ("alpha", F), ("act", I), ("accumulate", I),
+                ("A2", P), ("split_n", I), ("B2", P), ("split_m", I), ("C2", P), ("rowsum", P), ("rowsum_acc", I), ("rng", P),
+                ("a_drop_off", C.c_uint64), ("a_drop_n", C.c_uint64), ("a_drop_p", F), ("a_drop_p2", F),
+                ("c_drop_off", C.c_uint64), ("c_drop_n", C.c_uint64), ("c_drop_p", F), ("c_drop_p2", F)]
+
+
+class GatherJob(C.Structure):
+    """struct cwf_gather_job (include/cwf_hip.h)"""
+    _fields_ = [("feats", P), ("index", P), ("head", P), ("out", P), ("head_bstride", L), ("out_bstride", L), ("T", I),
+                ("drop_off", C.c_uint64)]
 RESTYPE_INT64 = {"cwf_wgrad_partial_floats", "cwf_wgrad_slab_floats"}
 
 _lib = None

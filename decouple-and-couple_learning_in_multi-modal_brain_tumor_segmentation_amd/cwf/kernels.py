@@ -73,6 +73,9 @@ class HipBackend:
         self._arena = {}
         self._arena_off = {}
         self._rng_counter = 0
+        self._rng = {}                         # device -> int64[2] {seed, step} (device-resident generator state)
+        self._rng_seed = {}
+        self._site = 0                         # per-step dropout-site offset (reset by begin_step, static across steps)
         self._wg_stream = {}                   # device -> side stream for weight gradients (opt-in, see wgrad_stream)
         self.wgrad_async = False
         self._rng_lock = threading.Lock()      # the autograd engine may call in from its own thread
@@ -103,7 +106,29 @@ class HipBackend:
     # within it; the arena is sized for forward + backward of a step with a generous margin and falls back to torch.zeros.
     ARENA_DOUBLES = 1 << 20
 
+    # ------------------------------------------------------------------ dropout generator (K12)
+    def rng(self, device):
+        """Device generator state {seed, step}.  The seed follows torch.initial_seed(); the step word is advanced by a kernel
+        in begin_step, so that a captured step draws fresh masks on every replay."""
+        device = torch.device(device)
+        st = self._rng.get(device)
+        seed = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF
+        if st is None or (self._rng_seed.get(device) != seed and not torch.cuda.is_current_stream_capturing()):
+            st = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+            self._rng[device] = st
+            self._rng_seed[device] = seed
+        return st
+
+    def rng_site(self, n):
+        """Counter offset of a dropout site of n elements (two chained masks may be drawn: 2n counters)."""
+        with self._rng_lock:
+            off = self._site
+            self._site = off + 2 * int(n)
+        return off
+
     def begin_step(self, device):
+        self._call("cwf_rng_advance", self.rng(device).data_ptr(), self._stream())
+        self._site = 0
         a = self._arena.get(device)
         if a is None:
             a = torch.zeros(self.ARENA_DOUBLES, dtype=torch.float64, device=device)
@@ -406,6 +431,192 @@ class HipBackend:
                    _p(dfeats), 0, _p(drows), e, k * e, _p(dgate), e, b, t, k, e, self._stream())
         return dfeats, drows, dgate
 
+    # ------------------------------------------------------------------ K6/K7, round-2 fused forms (one coupler block = 4 launches)
+    def _gemm_ex(self, **kw):
+        g = _lib.GemmArgs()
+        for k, v in kw.items():
+            setattr(g, k, v)
+        self._call("cwf_gemm_ex", ctypes.addressof(g), self._stream())
+
+    def _drop_kw(self, prefix, drop, numel, dev):
+        if not drop:
+            return {}
+        off, p, p2 = drop
+        return {prefix + "_off": off, prefix + "_n": numel, prefix + "_p": float(p), prefix + "_p2": float(p2), "rng": self.rng(dev).data_ptr()}
+
+    def linear_fwd(self, x, w, bias, out, x2=None, split_n=0, act=0, pre=None, drop=None, residual=None):
+        """out = drop(act(x' w^T + bias)) + residual ; x' = x for output columns < split_n, x2 beyond (2-D row-major views)."""
+        m, k = x.shape
+        n = w.shape[0]
+        assert x.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1 and out.shape == (m, n)
+        kw = dict(A=x.data_ptr(), sa_m=x.stride(0), sa_k=1, B=w.data_ptr(), sb_k=1, sb_n=w.stride(0), C=out.data_ptr(), sc_m=out.stride(0),
+                  bias=_p(bias), M=m, N=n, K=k, ZB=1, ZH=1, alpha=1.0, act=act)
+        if x2 is not None:
+            assert x2.stride() == x.stride() and x2.shape == x.shape
+            kw.update(A2=x2.data_ptr(), split_n=split_n)
+        if pre is not None:
+            assert pre.stride() == out.stride()
+            kw["C2"] = pre.data_ptr()
+        if residual is not None:
+            assert residual.stride(1) == 1
+            kw.update(residual=residual.data_ptr(), sr_m=residual.stride(0))
+        kw.update(self._drop_kw("c_drop", drop, m * n, x.device))
+        if drop:
+            assert out.stride(0) == n           # the mask index is the element offset inside out
+        self._gemm_ex(**kw)
+        return out
+
+    def linear_dgrad(self, dy, w, drop=None, out=None):
+        """dx = (dy * keep) w ; dy [M,N] (row stride from the view), w [N,K] view."""
+        m, n = dy.shape
+        k = w.shape[1]
+        assert dy.stride(1) == 1 and w.stride(1) == 1
+        dx = out if out is not None else torch.empty((m, k), dtype=_f32, device=dy.device)
+        kw = dict(A=dy.data_ptr(), sa_m=dy.stride(0), sa_k=1, B=w.data_ptr(), sb_k=w.stride(0), sb_n=1, C=dx.data_ptr(), sc_m=dx.stride(0),
+                  M=m, N=k, K=n, ZB=1, ZH=1, alpha=1.0)
+        kw.update(self._drop_kw("a_drop", drop, m * n, dy.device))
+        if drop:
+            assert dy.stride(0) == n
+        self._gemm_ex(**kw)
+        return dx
+
+    def linear_wgrad(self, dy, x, dw, dbias=None, x2=None, split_m=0, accumulate=False, drop=None):
+        """dw (+)= (dy * keep)^T x' ; dbias (+)= column sums of dy * keep ; x' = x for dw rows < split_m, x2 beyond."""
+        m, n = dy.shape
+        k = x.shape[1]
+        assert dy.stride(1) == 1 and x.stride(1) == 1 and dw.shape == (n, k) and dw.is_contiguous()
+        kw = dict(A=dy.data_ptr(), sa_m=1, sa_k=dy.stride(0), B=x.data_ptr(), sb_k=x.stride(0), sb_n=1, C=dw.data_ptr(), sc_m=k,
+                  M=n, N=k, K=m, ZB=1, ZH=1, alpha=1.0, accumulate=int(accumulate))
+        if x2 is not None:
+            assert x2.stride() == x.stride()
+            kw.update(B2=x2.data_ptr(), split_m=split_m)
+        if dbias is not None:
+            kw.update(rowsum=dbias.data_ptr(), rowsum_acc=int(accumulate))
+        kw.update(self._drop_kw("a_drop", drop, m * n, dy.device))
+        if drop:
+            assert dy.stride(0) == n
+        self._gemm_ex(**kw)
+
+    def ln_pair_fwd(self, x, x2, perm_T, g1, b1, g2, b2, eps=1e-5):
+        rows, e = x.shape
+        ya = torch.empty_like(x)
+        yb = torch.empty_like(x) if x2 is not None else None
+        stats = torch.empty((2 if x2 is not None else 1, rows, 2), dtype=_f32, device=x.device)
+        self._call("cwf_ln_pair_fwd", x.data_ptr(), _p(x2), perm_T, g1.data_ptr(), b1.data_ptr(), _p(g2), _p(b2), ya.data_ptr(), _p(yb),
+                   stats.data_ptr(), rows, e, eps, self._stream())
+        return ya, yb, stats
+
+    def ln_pair_bwd(self, dy, da, db, x, x2, perm_T, g1, g2, stats, dg1, db1, dg2, db2, accumulate, want_dx2):
+        rows, e = x.shape
+        dx = torch.empty_like(x)
+        dx2 = torch.empty_like(x) if want_dx2 else None
+        self._call("cwf_ln_pair_bwd", _p(dy), da.data_ptr(), _p(db), x.data_ptr(), _p(x2), perm_T, g1.data_ptr(), _p(g2), stats.data_ptr(),
+                   dx.data_ptr(), _p(dx2), dg1.data_ptr(), db1.data_ptr(), _p(dg2), _p(db2), rows, e, int(accumulate), self._stream())
+        return dx, dx2
+
+    def attn_fwd(self, qkv, z, t, heads, drop=None):
+        e = qkv.shape[1] // 3
+        o = torch.empty((z * t, e), dtype=_f32, device=qkv.device)
+        off, p = (drop[0], drop[1]) if drop else (0, 0.0)
+        self._call("cwf_attn_fwd", qkv.data_ptr(), qkv.stride(0), o.data_ptr(), e, z, t, e, heads, float((e // heads) ** -0.5),
+                   self.rng(qkv.device).data_ptr(), off, float(p), self._stream())
+        return o
+
+    def attn_bwd(self, qkv, d_o, z, t, heads, drop=None):
+        e = qkv.shape[1] // 3
+        assert d_o.is_contiguous()
+        dqkv = torch.empty_like(qkv)
+        off, p = (drop[0], drop[1]) if drop else (0, 0.0)
+        self._call("cwf_attn_bwd", qkv.data_ptr(), qkv.stride(0), d_o.data_ptr(), e, dqkv.data_ptr(), z, t, e, heads,
+                   float((e // heads) ** -0.5), self.rng(qkv.device).data_ptr(), off, float(p), self._stream())
+        return dqkv
+
+    def gelu_bwd_drop(self, z, dh, drop=None):
+        dz = torch.empty_like(z)
+        off, p = (drop[0], drop[1]) if drop else (0, 0.0)
+        self._call("cwf_gelu_bwd_drop", z.data_ptr(), dh.data_ptr(), dz.data_ptr(), z.numel(), self.rng(z.device).data_ptr(), off, float(p), self._stream())
+        return dz
+
+    # ------------------------------------------------------------------ K4/K5, round-2 forms
+    def token_scores2(self, feats, q1, q2=None):
+        b, t, e = feats.shape
+        s1 = torch.empty((b, t), dtype=_f32, device=feats.device)
+        s2 = torch.empty((b, t), dtype=_f32, device=feats.device) if q2 is not None else None
+        self._call("cwf_token_scores2", feats.data_ptr(), q1.data_ptr(), 0 if q1.shape[0] == 1 else e, _p(q2),
+                   0 if (q2 is None or q2.shape[0] == 1) else e, s1.data_ptr(), _p(s2), b, t, e, self._stream())
+        return s1, s2
+
+    def topk_inv(self, s0, s1, k):
+        """-> (index0, inv0, index1, inv1); the second pair is None when s1 is None."""
+        b, t = s0.shape
+        i32 = torch.int32
+        idx0 = torch.empty((b, k), dtype=i32, device=s0.device); inv0 = torch.empty((b, t), dtype=i32, device=s0.device)
+        idx1 = inv1 = None
+        if s1 is not None:
+            idx1 = torch.empty((b, k), dtype=i32, device=s0.device); inv1 = torch.empty((b, t), dtype=i32, device=s0.device)
+        self._call("cwf_topk_inv", s0.data_ptr(), idx0.data_ptr(), inv0.data_ptr(), _p(s1), _p(idx1), _p(inv1), b, t, k, self._stream())
+        return idx0, inv0, idx1, inv1
+
+    def index_inv(self, index, t):
+        b, k = index.shape
+        index = index.to(torch.int32).contiguous()
+        inv = torch.empty((b, t), dtype=torch.int32, device=index.device)
+        self._call("cwf_index_inv", index.data_ptr(), inv.data_ptr(), b, t, k, self._stream())
+        return index, inv
+
+    def gather_multi(self, jobs, k, e, p=0.0, pe_odd=1.0):
+        """jobs: list of (feats [B,T,E], index [B,k], head [1|B,1,E], out view [B,k+1,E] with contiguous rows, drop_off)."""
+        arr = (_lib.GatherJob * len(jobs))()
+        b = jobs[0][0].shape[0]
+        for i, (feats, index, head, out, off) in enumerate(jobs):
+            assert out.stride(2) == 1 and out.stride(1) == e and feats.is_contiguous()
+            arr[i] = _lib.GatherJob(feats.data_ptr(), index.data_ptr(), head.data_ptr(), out.data_ptr(), 0 if head.shape[0] == 1 else e,
+                                    out.stride(0), feats.shape[1], off)
+        self._call("cwf_gather_multi", ctypes.addressof(arr), len(jobs), b, k, e, float(pe_odd), self.rng(jobs[0][0].device).data_ptr(), float(p), self._stream())
+
+    def scatter_inv(self, feats, inv, rows, gate, want_gated=True, want_scat=False):
+        """rows [B,k,E] / gate [B,1,E] views with unit inner stride -> (gated, scat)"""
+        b, t, e = feats.shape
+        gated = torch.empty_like(feats) if want_gated else None
+        scat = torch.empty_like(feats) if want_scat else None
+        self._call("cwf_scatter_inv", feats.data_ptr(), inv.data_ptr(), rows.data_ptr(), rows.stride(1), rows.stride(0), _p(gate),
+                   gate.stride(0) if gate is not None else 0, _p(gated), _p(scat), b, t, e, self._stream())
+        return gated, scat
+
+    def scatter_bwd(self, dgated, dscat, feats, inv, index, rows, gate, dgate_extra, drows, dgate):
+        """writes drows [B,k,E] view and dgate [B,1,E] view (both inside the coupler's output gradient)"""
+        b, t, e = feats.shape
+        k = index.shape[1]
+        self._call("cwf_scatter_bwd", _p(dgated), _p(dscat), feats.data_ptr(), inv.data_ptr(), index.data_ptr(), rows.data_ptr(), rows.stride(1),
+                   rows.stride(0), _p(gate), gate.stride(0) if gate is not None else 0, _p(dgate_extra),
+                   dgate_extra.stride(0) if dgate_extra is not None else 0, drows.data_ptr(), drows.stride(1), drows.stride(0),
+                   dgate.data_ptr(), dgate.stride(0), b, t, k, e, self._stream())
+
+    def token_grad(self, dgated, dscat, gate, inv_p, inv_q, dseq_p, dseq_q, k, p=0.0, off_p=0, off_q=0):
+        b, t = inv_p.shape
+        e = dseq_p.shape[2]
+        dfeats = torch.empty((b, t, e), dtype=_f32, device=dseq_p.device)
+        self._call("cwf_token_grad", _p(dgated), _p(dscat), _p(gate), gate.stride(0) if gate is not None else 0, inv_p.data_ptr(), _p(inv_q),
+                   dseq_p.data_ptr(), dseq_p.stride(0), _p(dseq_q), dseq_q.stride(0) if dseq_q is not None else 0,
+                   self.rng(dseq_p.device).data_ptr(), off_p, off_q, float(p), dfeats.data_ptr(), b, t, k, e, self._stream())
+        return dfeats
+
+    def head_grad(self, a1, c1, a2, c2):
+        """out1 = sum_b (a1[b] + c1[b]), out2 = sum_b (a2[b] + c2[b]); inputs are [B,E] row views with a common batch stride"""
+        b, e = a1.shape
+        bs = a1.stride(0)
+        assert c1.stride(0) == bs and a2.stride(0) == bs and c2.stride(0) == bs
+        o1 = torch.empty((1, 1, e), dtype=_f32, device=a1.device)
+        o2 = torch.empty((1, 1, e), dtype=_f32, device=a1.device)
+        self._call("cwf_head_grad", a1.data_ptr(), c1.data_ptr(), a2.data_ptr(), c2.data_ptr(), bs, o1.data_ptr(), o2.data_ptr(), b, e, self._stream())
+        return o1, o2
+
+    def add3(self, a, b, c):
+        a, b, c = a.contiguous(), b.contiguous(), c.contiguous()
+        y = torch.empty_like(a)
+        self._call("cwf_add3", a.data_ptr(), b.data_ptr(), c.data_ptr(), y.data_ptr(), a.numel(), self._stream())
+        return y
+
     # ------------------------------------------------------------------ K8/K10
     def upsample_softmax(self, logit, c, scale):
         """logit [N,d,h,w,>=c] (channel stride from the tensor) -> prob [N,d*s,h*s,w*s,c]"""
@@ -460,21 +671,10 @@ class HipBackend:
                    _p(hyper_dev), self._stream())
 
     def dropout_mask(self, shape, p, device, p2=0.0):
-        """Pre-scaled keep mask(s) in one launch.  Counter-based: (torch seed, running element counter) -> reproducible for
-        a given seed and call order.  Under stream capture the counter could not advance between replays, so that case
-        uses torch's capture-aware generator instead."""
-        if torch.cuda.is_current_stream_capturing():
-            m = (torch.rand(shape, device=device) >= p).to(_f32) * (1.0 / (1.0 - p))
-            if p2 > 0.0:
-                m = m * ((torch.rand(shape, device=device) >= p2).to(_f32) * (1.0 / (1.0 - p2)))
-            return m
+        """Pre-scaled keep mask(s) in one launch from the device generator state (capturable: the state advances by a kernel)."""
         m = torch.empty(shape, dtype=_f32, device=device)
         n = m.numel()
-        seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
-        with self._rng_lock:
-            off = self._rng_counter
-            self._rng_counter = (off + 2 * n) & 0xFFFFFFFFFFFFFFFF
-        self._call("cwf_dropout_mask", m.data_ptr(), n, float(p), float(p2), seed, off, self._stream())
+        self._call("cwf_dropout_mask_rng", m.data_ptr(), n, float(p), float(p2), self.rng(device).data_ptr(), self.rng_site(n), self._stream())
         return m
 
     def mul(self, a, b):

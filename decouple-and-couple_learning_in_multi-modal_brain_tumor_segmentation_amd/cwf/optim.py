@@ -8,8 +8,6 @@ train_no_amp.adjust_learning_rate (:270-273).
 
 Gradients are gathered into ONE persistent flat fp32 buffer (``flat_grad``, 67 MB): the kernel's descriptor table is
 then static (safe for hipGraph capture / replay) and data-parallel training all-reduces that single buffer."""
-import math
-
 import numpy as np
 import torch
 
@@ -29,18 +27,33 @@ class FusedAdam(torch.optim.Optimizer):
         self.flat_grad = None
         self._table = None
         self._max_n = 0
-        self._hyper_dev = None
-        self._hyper_host = None
         self._steps = 0
 
     # ------------------------------------------------------------------ setup
+    def _key(self):
+        """Everything the descriptor table points at: parameters AND state tensors (load_state_dict replaces the latter)."""
+        k = []
+        for p in self._plist:
+            st = self.state.get(p) or {}
+            k.append((p.data_ptr(),) + tuple(st[n].data_ptr() if n in st else 0 for n in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq")))
+        return tuple(k)
+
+    def load_state_dict(self, state_dict):
+        """torch semantics; additionally the descriptor table is rebuilt (the moments are new tensors) and the step counter
+        continues from the loaded 'step' (train_no_amp.py:252 saves it inside 'optim_dict')."""
+        super().load_state_dict(state_dict)
+        self._table = None
+        steps = [int(float(self.state[p]["step"])) for p in self._plist if p in self.state and "step" in self.state[p]]
+        self._steps = max(steps) if steps else 0
+
     def _ensure(self):
-        if self._table is not None and self._table_key == tuple(p.data_ptr() for p in self._plist):
+        if self._table is not None and self._table_key == self._key():
             return
         group = self.param_groups[0]
         dev = self._plist[0].device
         total = sum(p.numel() for p in self._plist)
-        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        if self.flat_grad is None or self.flat_grad.numel() != total or self.flat_grad.device != dev:
+            self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         rows, off = [], 0
         for p in self._plist:
             st = self.state[p]
@@ -55,10 +68,8 @@ class FusedAdam(torch.optim.Optimizer):
                          st["max_exp_avg_sq"].data_ptr() if "max_exp_avg_sq" in st else 0, n])
             off += n
         self._table = torch.tensor(rows, dtype=torch.int64).to(dev)
-        self._table_key = tuple(p.data_ptr() for p in self._plist)
+        self._table_key = self._key()
         self._max_n = max(r[5] for r in rows)
-        self._hyper_dev = torch.zeros(2, dtype=torch.float32, device=dev)
-        self._hyper_host = torch.zeros(2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(2)
 
     # ------------------------------------------------------------------ the three phases of a step
     def gather_grads(self):
@@ -68,26 +79,20 @@ class FusedAdam(torch.optim.Optimizer):
         return self.flat_grad
 
     def advance_host(self):
-        """Host side of a step: step counter, bias corrections (double, as torch) -> device hyper buffer.  Call BEFORE
-        launching / replaying the kernel of the step."""
+        """Host side of a step: the step counter.  Call BEFORE launch()."""
         self._ensure()
-        group = self.param_groups[0]
         self._steps += 1
         for p in self._plist:
             self.state[p]["step"] += 1
-        b1, b2 = group["betas"]
-        bc1 = 1.0 - b1 ** self._steps
-        bc2 = 1.0 - b2 ** self._steps
-        self._hyper_host[0] = group["lr"] / bc1
-        self._hyper_host[1] = math.sqrt(bc2)
-        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
 
     def launch(self):
-        """The single fused kernel (capturable: every argument is static, the schedule lives in the device hyper buffer)."""
+        """The single fused kernel.  lr and the step number travel as KERNEL ARGUMENTS (copied at enqueue time; the bias
+        corrections are evaluated in double inside cwf_adam_amsgrad): nothing the host rewrites later is read by the GPU, so
+        any number of steps may be in flight.  The launch is issued eagerly after a graph replay (it is not captured)."""
         group = self.param_groups[0]
         b1, b2 = group["betas"]
         backend().adam(self._table, len(self._plist), self._max_n, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
-                       0, group["amsgrad"], hyper_dev=self._hyper_dev)
+                       self._steps, group["amsgrad"], hyper_dev=None)
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -11,8 +11,7 @@ Deliberate relaxations of reference limitations:
   * no ``fix_index.txt`` (F1): the row scatter is done on device from the top-k indices, with no host sync
     (the reference does 7 x 128 ``.item()`` round trips per forward, cls_wise_former.py:463-572);
   * batch > 1 = independent samples with the reference's B=1 semantics (F2);
-  * sizes derive from the input (F3): D,H,W divisible by 16 (D by 16 for the (4,2,2) edge windows) and at least
-    128 semantic tokens;
+  * sizes derive from the input (F3): D,H,W divisible by 16 and at least 128 semantic tokens (D*H*W >= 64^3), checked in forward;
   * the always-on stem dropout (F4) is kept by default; set ``model.Unet_list.InitConv.dropout = 0.0`` to disable.
 Returned tensors are logical NC(DHW) views of channels-last (NDHWC) memory.
 """
@@ -20,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from cwf import functional as CF
+from cwf import coupler as CP
 from cwf.kernels import backend
 from .layers import HipConv, collect_convs
 from .Unet_skipconnection import Unet
@@ -81,16 +81,12 @@ class ClsWiseFormer(nn.Module):
         self._streams = None
 
     # ------------------------------------------------------------------------------------------------
-    def _select(self, feats, score_tok, head, name):
-        k = min(self.top_num, feats.shape[1])
-        keep = None
-        if self.training and self.dropout_rate > 0:
-            keep = CF.dropout_mask((feats.shape[0], k, feats.shape[2]), self.dropout_rate, feats.device)
-        forced = self.forced_index.get(name) if self.forced_index else None
-        seq, idx = CF.select_tokens(feats, score_tok, head, k, keep, forced)
-        if self.collect_aux:
-            self.aux[name] = idx
-        return seq, idx
+    def _coupler_cfg(self, tr, names):
+        """Dropout rates are read from the module tree at call time (tests zero them; the reference's values are 0.1)."""
+        pre = tr.cross_attention_list[0].fn
+        ff = tr.cross_ffn_list[0].fn.fn
+        return CP.CouplerConfig(self.num_heads, self.top_num, self.training, self.dropout_rate, pre.fn.dropout_rate, pre.dropout_rate,
+                                ff.dropout_rate, forced=self.forced_index, names=names)
 
     def _region(self, r, k, x23, x4):
         """Everything that belongs to ONE sub-region (label 1 / 2 / 4): decoupler convs, mid heads, token selection,
@@ -104,21 +100,20 @@ class ClsWiseFormer(nn.Module):
         sem_size, edge_size = tuple(sf.shape[1:4]), tuple(ef.shape[1:4])
         E = CF.window_to_tokens(ef, self.edge_patch_size)        # [B,Ne,512]  :341
         S = CF.window_to_tokens(sf, self.patch_size)             # [B,Ns,512]  :342
-        e_tok, s_tok = getattr(self, "e_token_" + r), getattr(self, "s_token_" + r)
-        edge_seq, idx_e = self._select(E, e_tok, e_tok, r + "_edge")           # :345-350
-        sem_supp, _ = self._select(S, e_tok, s_tok, r + "_sem_supp")           # :352-357 scored by e_tok, headed by s_tok
-        sem_seq, idx_s = self._select(S, s_tok, s_tok, r + "_sem")             # :360-367
-        edge_supp, _ = self._select(E, s_tok, e_tok, r + "_edge_supp")         # :370-376 scored by s_tok, headed by e_tok
-        res = getattr(self, "transformer_" + r)(edge_seq, sem_supp, sem_seq, edge_supp)     # :379  [B,258,512]
-        n1 = edge_seq.shape[1]
-        gated_e, _ = CF.scatter_gate(E, idx_e, res[:, 1:n1], res[:, 0:1])                   # :467,481
-        gated_s, scat_s = CF.scatter_gate(S, idx_s, res[:, n1 + 1:2 * n1], res[:, n1:n1 + 1])   # :477,484
+        # selection (:345-376) -> Edge-supported Intra-region Coupler (:379) -> scatter + gate (:463-485): one fused Function
+        names = (r + "_edge", r + "_sem_supp", r + "_sem", r + "_edge_supp")
+        tr = getattr(self, "transformer_" + r)
+        out = CP.RegionCouplerFn.apply(self._coupler_cfg(tr, names), E, S, getattr(self, "e_token_" + r), getattr(self, "s_token_" + r),
+                                       *CP.transformer_params(tr))
+        gated_e, gated_s, scat_s, sem_tok = out[:4]
+        if self.collect_aux:
+            for nm, idx in zip(names, out[4:]):
+                self.aux[nm] = idx
         sup_edge = CF.tokens_to_window(gated_e, edge_size, self.edge_feature_n, self.edge_patch_size)
         sup_sem = CF.tokens_to_window(gated_s, sem_size, self.item_feature_n, self.patch_size)
         sup = self.supervise_label.head(k, sup_sem)                                  # :545
         edge = self.edge_supervise_label.head(k, sup_edge)                           # :546
-        return dict(mid_sup=mid_sup, mid_edge=mid_edge, sup=sup, edge=edge, sem_token=res[:, n1:n1 + 1], sem_after=scat_s,
-                    sem_size=sem_size)
+        return dict(mid_sup=mid_sup, mid_edge=mid_edge, sup=sup, edge=edge, sem_token=sem_tok, sem_after=scat_s, sem_size=sem_size)
 
     def encode(self, x, missing_modal=None):
         x1, x2, x3, x4 = self.Unet_list(x)
@@ -157,11 +152,12 @@ class ClsWiseFormer(nn.Module):
         sem_size = outs[0]["sem_size"]
 
         # Mutual Cross-region Coupler (:549-579): post-scatter UN-gated semantic tokens are fused
-        f_tok = CF.add(CF.add(sem_tokens[0], sem_tokens[1]), sem_tokens[2])
-        f_feat = CF.add(CF.add(sem_after[0], sem_after[1]), sem_after[2])
-        f_seq, f_idx = self._select(f_feat, f_tok, f_tok, "fusion")
-        f_res = self.fusion_transformer_1_2_4(f_seq)
-        fused, _ = CF.scatter_gate(f_feat, f_idx, f_res[:, 1:], f_res[:, 0:1])
+        f_tok = CP.add3(sem_tokens[0], sem_tokens[1], sem_tokens[2])
+        f_feat = CP.add3(sem_after[0], sem_after[1], sem_after[2])
+        tr = self.fusion_transformer_1_2_4
+        fused, f_idx = CP.FusionCouplerFn.apply(self._coupler_cfg(tr, ("fusion",)), f_feat, f_tok, *CP.transformer_params(tr))
+        if self.collect_aux:
+            self.aux["fusion"] = f_idx
         xb = CF.tokens_to_window(fused, sem_size, self.item_feature_n, self.patch_size)
         xb, _ = self.sum_fusion(xb)                                   # :582
         if self.collect_aux:
@@ -173,8 +169,13 @@ class ClsWiseFormer(nn.Module):
         if x.dim() != 5 or x.shape[1] != 4:
             raise ValueError("expected x of shape [B,4,D,H,W], got %s" % (tuple(x.shape),))
         _, _, d, h, w = x.shape
-        if d % 16 or h % 16 or w % 16 or (d // 8) * (h // 8) * (w // 8) // 4 < 1:
+        if d % 16 or h % 16 or w % 16:
             raise ValueError("D, H, W must be multiples of 16 (got %d,%d,%d)" % (d, h, w))
+        if (d // 16) * (h // 16) * (w // 8) < self.top_num:
+            # every selection takes exactly top_num rows, so that the four sequences of a region have one length and the coupler
+            # runs as batches of sequence pairs (the reference's own sizes give 1024 / 2048 tokens)
+            raise ValueError("the patch must yield at least %d semantic tokens: D*H*W >= %d (got %dx%dx%d)"
+                             % (self.top_num, self.top_num * 2048, d, h, w))
         self.aux = {}
         backend().begin_step(x.device)
         self._packer.refresh()

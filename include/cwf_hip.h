@@ -151,6 +151,59 @@ int cwf_gemm(const float* A, int64_t sa_m, int64_t sa_k, int64_t sa_zb, int64_t 
              float* C, int64_t sc_m, int64_t sc_zb, int64_t sc_zh,
              const float* bias, const float* residual, int64_t sr_m, int64_t sr_zb, int64_t sr_zh,
              int M, int Nn, int K, int ZB, int ZH, float alpha, int act, int accumulate, void* stream);
+/* Extended form: the same product with the fusions that keep a coupler block at a handful of launches.  Zero-initialise the
+ * struct; fields beyond `accumulate` are optional.
+ *   A2/split_n   output columns n >= split_n read A2 (same strides) instead of A: q = LN1(x) Wq^T and k|v = LN2(x2) Wkv^T over the
+ *                reference's single [1536,512] qkv weight in ONE launch (SelfAttention.py:80-93); split_n % 64 == 0
+ *   B2/split_m   output rows m >= split_m read B2: the weight gradient [dq^T a ; dkv^T b] of the same layer in one launch
+ *   C2           receives alpha*AB + bias BEFORE the activation (the GELU input, kept for backward; ResidualNorm.py:40-41)
+ *   rowsum       rowsum[m] (+)= sum_k A'(m,k): with A' = dy^T this is the bias gradient of a Linear, from one extra MFMA
+ *   a_drop_*     A' = A * keep(offset of the element inside A): dropout of dy recomputed, not stored (backward of
+ *                x + Dropout(Linear(.)), ResidualNorm.py:9-10,25-31); *_n = numel of the dropped tensor, p2 = a second chained dropout
+ *   c_drop_*     epilogue order: alpha*AB + bias -> C2 -> act -> dropout -> + residual -> (accumulate) -> C
+ *   rng          device uint64[2] {seed, step} (cwf_rng_advance)                                                           */
+struct cwf_gemm_args {
+  const float* A; int64_t sa_m, sa_k, sa_zb, sa_zh;
+  const float* B; int64_t sb_k, sb_n, sb_zb, sb_zh;
+  float* C; int64_t sc_m, sc_zb, sc_zh;
+  const float* bias; const float* residual; int64_t sr_m, sr_zb, sr_zh;
+  int M, N, K, ZB, ZH; float alpha; int act; int accumulate;
+  const float* A2; int split_n;
+  const float* B2; int split_m;
+  float* C2;
+  float* rowsum; int rowsum_acc;
+  const uint64_t* rng;
+  uint64_t a_drop_off, a_drop_n; float a_drop_p, a_drop_p2;
+  uint64_t c_drop_off, c_drop_n; float c_drop_p, c_drop_p2;
+};
+int cwf_gemm_ex(const struct cwf_gemm_args* args /* host */, void* stream);
+
+/* The attention core of one coupler block in one launch each way (SelfAttention.py:94-98; K6):
+ *   qkv [Z*T][ld] holds q | k | v side by side (columns [0,E) [E,2E) [2E,3E), head-major), T <= 144, E = heads*64
+ *   o[z*T+t][h*64+d] = sum_key dropout(softmax_key(scale * q.k))[t][key] * v[key][d]
+ *   backward recomputes the probabilities in LDS: dqkv (same layout as qkv) from d_o.  Attention dropout is keep(drop_off +
+ *   ((z*heads+h)*T + t)*T + key) from the device generator state -- no mask tensor, no [Z,heads,T,T] probabilities in HBM. */
+int cwf_attn_fwd(const float* qkv, int64_t ld, float* o, int64_t ldo, int Z, int T, int E, int heads, float scale,
+                 const uint64_t* rng, uint64_t drop_off, float drop_p, void* stream);
+int cwf_attn_bwd(const float* qkv, int64_t ld, const float* d_o, int64_t ldo, float* dqkv, int Z, int T, int E, int heads,
+                 float scale, const uint64_t* rng, uint64_t drop_off, float drop_p, void* stream);
+
+/* Paired LayerNorm of a coupler block (PreNormDrop: norm(x), norm2(x2); ResidualNorm.py:23-32):
+ *   ya = LN(x; g1,b1) ; yb[r] = LN(x2[perm(r)]; g2,b2) ; stats [2][rows][2] = (mean, rstd) ; x2 may be NULL (PreNorm of the FFN)
+ *   perm_T > 0: the second operand is read with the two halves of every sequence pair swapped (rows = pairs * 2 * perm_T),
+ *   which is how "a attends b, b attends a" (ClsWiseTransformer.py:47-50) runs as one batch.
+ * backward (one launch for the inputs, one for the four parameter gradients, both deterministic, nothing pre-zeroed):
+ *   dx2 != NULL:  dx = dy + LN1'(da) ; dx2 = LN2'(db)                    (perm_T == 0)
+ *   dx2 == NULL:  dx[r] = dy[r] + LN1'(da[r]) + LN2'(db[perm(r)])        (x2 is x; db may be NULL -> single LayerNorm)
+ *   dg*, db* (+)= per-column sums (accumulate_params: the weight-sharing sum over the uses of one block)                  */
+int cwf_ln_pair_fwd(const float* x, const float* x2, int perm_T, const float* g1, const float* b1, const float* g2, const float* b2,
+                    float* ya, float* yb, float* stats, int rows, int E, float eps, void* stream);
+int cwf_ln_pair_bwd(const float* dy, const float* da, const float* db, const float* x, const float* x2, int perm_T,
+                    const float* g1, const float* g2, const float* stats, float* dx, float* dx2,
+                    float* dg1, float* db1, float* dg2, float* db2, int rows, int E, int accumulate_params, void* stream);
+/* dz = dh * keep(off + i) * gelu'(z)      backward of Dropout(GELU(z)), mask recomputed (p may be 0) */
+int cwf_gelu_bwd_drop(const float* z, const float* dh, float* dz, int64_t n, const uint64_t* rng, uint64_t off, float p, void* stream);
+
 /* rows x E LayerNorm (eps 1e-5): y = (x-mean)*rstd*gamma+beta; saves mean/rstd [rows] */
 int cwf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                       int rows, int E, float eps, void* stream);
@@ -196,6 +249,41 @@ int cwf_scatter_rows(const float* feats, const int32_t* index, const float* rows
 int cwf_scatter_rows_bwd(const float* dout, const int32_t* index, const float* scat, const float* gate, int64_t gate_bs,
                          float* dfeats, int accumulate, float* drows, int64_t drows_ld, int64_t drows_bs,
                          float* dgate, int64_t dgate_bs, int B, int T, int k, int E, void* stream);
+
+/* ---- round-2 forms: one launch per stage of a sub-region's selection / scatter, gradients written (not accumulated) ------- */
+/* s1[b][t] = feats[b][t].q1[b or 0], s2 likewise for q2 (nullable): both class tokens of a region against one token matrix */
+int cwf_token_scores2(const float* feats, const float* q1, int64_t q1_bstride, const float* q2, int64_t q2_bstride,
+                      float* s1, float* s2, int B, int T, int E, void* stream);
+/* top-k of one or two score vectors [B][T] (same T, k) in one launch; inv*[b][t] = rank of token t if selected else -1 (nullable);
+ * NaN scores order as the largest value (torch.topk) */
+int cwf_topk_inv(const float* score0, int32_t* index0, int32_t* inv0, const float* score1, int32_t* index1, int32_t* inv1,
+                 int B, int T, int k, void* stream);
+/* inverse map of a given index set (teacher-forced selections in tests) */
+int cwf_index_inv(const int32_t* index, int32_t* inv, int B, int T, int k, void* stream);
+/* up to four gathers in one launch: out[b][0] = head[b or 0] ; out[b][1+j] = (feats[b][index[b][j]] + pe) * keep
+ * (the four 129-token sequences of a region written straight into the paired [B][2][129][E] operands; :345-376) */
+struct cwf_gather_job { const float* feats; const int32_t* index; const float* head; float* out;
+                        int64_t head_bstride, out_bstride; int T; uint64_t drop_off; };
+int cwf_gather_multi(const struct cwf_gather_job* jobs /* host */, int njobs, int B, int k, int E, float pe_odd,
+                     const uint64_t* rng, float p, void* stream);
+/* scat = feats with the selected rows replaced (via inv) ; gated = scat * gate ; either output may be NULL      (:463-485) */
+int cwf_scatter_inv(const float* feats, const int32_t* inv, const float* rows, int64_t rows_ld, int64_t rows_bs,
+                    const float* gate, int64_t gate_bs, float* gated, float* scat, int B, int T, int E, void* stream);
+/* backward of the above into the producer of (rows, gate): drows[b][j] = dgated[b][index[j]]*gate + dscat[b][index[j]] ;
+ * dgate[b] = sum_t dgated*scat + dgate_extra[b]   (scat re-derived from feats / inv / rows; written, deterministic) */
+int cwf_scatter_bwd(const float* dgated, const float* dscat, const float* feats, const int32_t* inv, const int32_t* index,
+                    const float* rows, int64_t rows_ld, int64_t rows_bs, const float* gate, int64_t gate_bs,
+                    const float* dgate_extra, int64_t extra_bs, float* drows, int64_t drows_ld, int64_t drows_bs,
+                    float* dgate, int64_t dgate_bs, int B, int T, int k, int E, void* stream);
+/* gradient of a token matrix from its three uses in one pass (written): scatter pass-through of the non-selected rows
+ * (dgated*gate + dscat) + adjoint of the primary gather (inv_p, dseq_p) + adjoint of the supplementary gather (inv_q, dseq_q) */
+int cwf_token_grad(const float* dgated, const float* dscat, const float* gate, int64_t gate_bs,
+                   const int32_t* inv_p, const int32_t* inv_q, const float* dseq_p, int64_t dseq_p_bs,
+                   const float* dseq_q, int64_t dseq_q_bs, const uint64_t* rng, uint64_t drop_off_p, uint64_t drop_off_q, float p,
+                   float* dfeats, int B, int T, int k, int E, void* stream);
+/* class-token gradients: out1 = sum_b (a1[b] + c1[b]), out2 = sum_b (a2[b] + c2[b]) over rows of stride bstride */
+int cwf_head_grad(const float* a1, const float* c1, const float* a2, const float* c2, int64_t bstride,
+                  float* out1, float* out2, int B, int E, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K8/K10  heads: trilinear upsample (align_corners=False) + channel softmax; 4-class channel softmax
@@ -246,8 +334,14 @@ int cwf_adam_amsgrad(const struct cwf_adam_desc* table, int ntensors, int64_t ma
 /* K12: mask[i] = Bernoulli(1-p)/(1-p) [* Bernoulli(1-p2)/(1-p2)], counter-based (seed, offset + i): replaces the
  * rand / compare / cast / scale sequence behind F.dropout (SelfAttention.py:96-100, ResidualNorm.py:25-31,40-45) */
 int cwf_dropout_mask(float* mask, int64_t n, float p, float p2, uint64_t seed, uint64_t offset, void* stream);
+/* Device-resident generator state rng = uint64[2] {seed, step}.  cwf_rng_advance is a KERNEL (step += 1): captured in a hipGraph
+ * it advances on every replay, so replayed training steps draw fresh masks.  Every fused dropout site evaluates
+ * keep(i) = u01(seed, step, site_offset + i) >= p ? 1/(1-p) : 0 from the element index, forward and backward alike. */
+int cwf_rng_advance(uint64_t* rng, void* stream);
+int cwf_dropout_mask_rng(float* mask, int64_t n, float p, float p2, const uint64_t* rng, uint64_t offset, void* stream);
 int cwf_mul(const float* a, const float* b, float* y, int64_t n, void* stream);
 int cwf_add(const float* a, const float* b, float* y, int64_t n, void* stream);
+int cwf_add3(const float* a, const float* b, const float* c, float* y, int64_t n, void* stream);   /* (a + b) + c: the three-region sums of the Mutual Cross-region Coupler, cls_wise_former.py:549-552 */
 int cwf_channel_scale(const float* x, int x_ldc, const float* s, float* y, int y_ldc, int N, int64_t V, int C, void* stream);
 int cwf_copy_strided(const float* x, int x_ldc, float* y, int y_ldc, int64_t nvox, int C, void* stream);
 

@@ -57,8 +57,50 @@ def _fwd_conv(op, xa, w, b):
     return _ndhwc(y)
 
 
+_M64 = (1 << 64) - 1
+
+
+def _u01(seed, step, ctr):
+    """cwf_rng_u01 (csrc/common.h): splitmix64 of (seed + step * K, counter) -> float32 in [0, 1).  ctr: np.uint64 array."""
+    import numpy as np
+    key = np.uint64((seed + step * 0xD6E8FEB86659FD93) & _M64)
+    with np.errstate(over="ignore"):
+        z = (key ^ np.uint64(0x9E3779B97F4A7C15)) + ctr * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+
 class EmulBackend:
     name = "emul"
+
+    def __init__(self):
+        self._seed = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF
+        self._step = 0
+        self._site = 0
+
+    # ------------------------------------------------------------------ K12: counter-based dropout (bit-exact with cwf_keep)
+    def set_rng(self, seed, step):
+        self._seed, self._step = int(seed), int(step)
+
+    def rng(self, device):
+        return torch.tensor([self._seed, self._step], dtype=torch.int64)
+
+    def rng_site(self, n):
+        off = self._site
+        self._site = off + 2 * int(n)
+        return off
+
+    def keep(self, off, n, p, p2=0.0):
+        """flat float32 [n]: keep(i) = [u01(off + i) >= p] / (1 - p)  (* the same for p2 at counter off + n + i)"""
+        import numpy as np
+        i = np.arange(n, dtype=np.uint64)
+        one = np.float32(1.0)
+        v = np.where(_u01(self._seed, self._step, np.uint64(off) + i) >= np.float32(p), one / (one - np.float32(p)), np.float32(0.0))
+        if p2 > 0.0:
+            v = v * np.where(_u01(self._seed, self._step, np.uint64(off + n) + i) >= np.float32(p2), one / (one - np.float32(p2)), np.float32(0.0))
+        return torch.from_numpy(v.astype(np.float32))
 
     # ------------------------------------------------------------------ K1
     def conv(self, op, x, wpk, bias, cout, in_scale=None, in_shift=None, slope=1.0, residual=None, out_scale=None,
@@ -101,7 +143,8 @@ class EmulBackend:
         return gw.reshape(-1), (gb if has_bias_map else None)
 
     def begin_step(self, device):
-        pass
+        self._step += 1
+        self._site = 0
 
     def gather_batched(self, table, nlayers, max_n, split_bf16=False):
         pass    # packed buffers are unused by the emulation
@@ -240,6 +283,195 @@ class EmulBackend:
         dfeats = g.scatter(1, idx, torch.zeros_like(drows))
         return dfeats, drows, dgate
 
+    # ------------------------------------------------------------------ K6/K7 round-2 fused forms
+    def _mask2d(self, drop, m, n):
+        if not drop:
+            return None
+        off, p, p2 = drop
+        return self.keep(off, m * n, p, p2).reshape(m, n)
+
+    def linear_fwd(self, x, w, bias, out, x2=None, split_n=0, act=0, pre=None, drop=None, residual=None):
+        """cwf_gemm_ex as nn.Linear (+ GELU, + Dropout, + residual): SelfAttention.py:80-102, ResidualNorm.py:35-47."""
+        v = x @ w.t()
+        if x2 is not None:
+            v[:, split_n:] = x2 @ w[split_n:].t()
+        if bias is not None:
+            v = v + bias
+        if pre is not None:
+            pre.copy_(v)
+        if act == 1:
+            v = F.gelu(v)
+        mk = self._mask2d(drop, *v.shape)
+        if mk is not None:
+            v = v * mk
+        if residual is not None:
+            v = v + residual
+        out.copy_(v)
+        return out
+
+    def linear_dgrad(self, dy, w, drop=None, out=None):
+        mk = self._mask2d(drop, *dy.shape)
+        d = dy * mk if mk is not None else dy
+        dx = d @ w
+        if out is not None:
+            out.copy_(dx)
+            return out
+        return dx
+
+    def linear_wgrad(self, dy, x, dw, dbias=None, x2=None, split_m=0, accumulate=False, drop=None):
+        mk = self._mask2d(drop, *dy.shape)
+        d = dy * mk if mk is not None else dy
+        g = d.t() @ x
+        if x2 is not None:
+            g[split_m:] = d[:, split_m:].t() @ x2
+        dw.copy_(g + dw if accumulate else g)
+        if dbias is not None:
+            dbias.copy_(d.sum(0) + dbias if accumulate else d.sum(0))
+
+    @staticmethod
+    def _perm(rows, perm_T, device=None):
+        r = torch.arange(rows)
+        return ((r // perm_T) ^ 1) * perm_T + r % perm_T if perm_T > 0 else r
+
+    def ln_pair_fwd(self, x, x2, perm_T, g1, b1, g2, b2, eps=1e-5):
+        """nn.LayerNorm(x), nn.LayerNorm(x2[perm]) (PreNormDrop, ResidualNorm.py:23-32) + (mean, rstd) per row."""
+        rows = x.shape[0]
+
+        def one(v, g, b):
+            mean = v.mean(-1)
+            rstd = 1.0 / torch.sqrt(v.var(-1, unbiased=False) + eps)
+            return (v - mean[:, None]) * rstd[:, None] * g + b, torch.stack((mean, rstd), -1)
+        ya, sa = one(x, g1, b1)
+        if x2 is None:
+            return ya, None, sa[None]
+        yb, sb = one(x2[self._perm(rows, perm_T)], g2, b2)
+        return ya, yb, torch.stack((sa, sb), 0)
+
+    def ln_pair_bwd(self, dy, da, db, x, x2, perm_T, g1, g2, stats, dg1, db1, dg2, db2, accumulate, want_dx2):
+        rows, e = x.shape
+
+        def lnb(d, v, g, st):
+            xh = (v - st[:, 0:1]) * st[:, 1:2]
+            gg = d * g
+            return st[:, 1:2] * (gg - gg.mean(-1, keepdim=True) - xh * (gg * xh).mean(-1, keepdim=True)), (d * xh).sum(0), d.sum(0)
+        dx1, pg, pb = lnb(da, x, g1, stats[0])
+        dg1.copy_(pg + dg1 if accumulate else pg); db1.copy_(pb + db1 if accumulate else pb)
+        dx = dx1 + dy if dy is not None else dx1
+        dx2 = None
+        if db is not None:
+            perm = self._perm(rows, perm_T)
+            d2, pg2, pb2 = lnb(db, x2[perm], g2, stats[1])       # gradient w.r.t. the permuted rows the second LayerNorm saw
+            dg2.copy_(pg2 + dg2 if accumulate else pg2); db2.copy_(pb2 + db2 if accumulate else pb2)
+            if want_dx2:
+                dx2 = d2
+            else:
+                dx = dx.index_add(0, perm, d2)                   # x2 is x: route back through the (involutive) permutation
+        return dx, dx2
+
+    def _attn(self, qkv, z, t, heads, drop):
+        e = qkv.shape[1] // 3
+        hd = e // heads
+        q, k, v = (qkv[:, i * e:(i + 1) * e].reshape(z, t, heads, hd).permute(0, 2, 1, 3) for i in range(3))
+        att = (torch.einsum("zhxd,zhyd->zhxy", q, k) * (hd ** -0.5)).softmax(-1)
+        if drop:
+            att = att * self.keep(drop[0], z * heads * t * t, drop[1]).reshape(z, heads, t, t)
+        return torch.einsum("zhxy,zhyd->zhxd", att, v).permute(0, 2, 1, 3).reshape(z * t, e)
+
+    def attn_fwd(self, qkv, z, t, heads, drop=None):
+        """softmax(q k^T / sqrt(d)) -> attn_drop -> @ v  (SelfAttention.py:94-98)"""
+        return self._attn(qkv, z, t, heads, drop)
+
+    def attn_bwd(self, qkv, d_o, z, t, heads, drop=None):
+        qq = qkv.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            o = self._attn(qq, z, t, heads, drop)
+            (g,) = torch.autograd.grad(o, qq, d_o)
+        return g
+
+    def gelu_bwd_drop(self, z, dh, drop=None):
+        g = self.gelu_bwd(z, dh)
+        if drop:
+            g = g * self.keep(drop[0], z.numel(), drop[1]).reshape(z.shape)
+        return g
+
+    # ------------------------------------------------------------------ K4/K5 round-2 forms
+    def token_scores2(self, feats, q1, q2=None):
+        return self.token_scores(feats, q1), (self.token_scores(feats, q2) if q2 is not None else None)
+
+    def _inv(self, index, t):
+        b, k = index.shape
+        inv = torch.full((b, t), -1, dtype=torch.int32)
+        inv.scatter_(1, index.long(), torch.arange(k, dtype=torch.int32)[None].expand(b, -1))
+        return inv
+
+    def topk_inv(self, s0, s1, k):
+        def one(s):
+            s = torch.where(torch.isnan(s), torch.full_like(s, float("inf")), s)
+            idx = self.topk(s, k)
+            return idx, self._inv(idx, s.shape[1])
+        i0, v0 = one(s0)
+        if s1 is None:
+            return i0, v0, None, None
+        i1, v1 = one(s1)
+        return i0, v0, i1, v1
+
+    def index_inv(self, index, t):
+        index = index.to(torch.int32).contiguous()
+        return index, self._inv(index, t)
+
+    def gather_multi(self, jobs, k, e, p=0.0, pe_odd=1.0):
+        for feats, index, head, out, off in jobs:
+            b = feats.shape[0]
+            keep = self.keep(off, b * k * e, p).reshape(b, k, e) if p > 0.0 else None
+            out.copy_(self.gather_tokens(feats, index, head, keep, pe_odd))
+
+    def scatter_inv(self, feats, inv, rows, gate, want_gated=True, want_scat=False):
+        sel = (inv >= 0)[:, :, None]
+        picked = torch.gather(rows, 1, inv.clamp_min(0).long()[:, :, None].expand(-1, -1, feats.shape[2]))
+        scat = torch.where(sel, picked, feats)
+        return (scat * gate if want_gated else None), (scat if want_scat else None)
+
+    def scatter_bwd(self, dgated, dscat, feats, inv, index, rows, gate, dgate_extra, drows, dgate):
+        b, t, e = feats.shape
+        idx = index.long()[:, :, None].expand(-1, -1, e)
+        g = torch.zeros((b, t, e))
+        dg = torch.zeros((b, 1, e))
+        if dgated is not None:
+            _, scat = self.scatter_inv(feats, inv, rows, None, want_gated=False, want_scat=True)
+            g = g + dgated * gate
+            dg = dg + (dgated * scat).sum(1, keepdim=True)
+        if dscat is not None:
+            g = g + dscat
+        if dgate_extra is not None:
+            dg = dg + dgate_extra
+        drows.copy_(torch.gather(g, 1, idx))
+        dgate.copy_(dg)
+
+    def token_grad(self, dgated, dscat, gate, inv_p, inv_q, dseq_p, dseq_q, k, p=0.0, off_p=0, off_q=0):
+        b, t = inv_p.shape
+        e = dseq_p.shape[2]
+        g = torch.zeros((b, t, e))
+        if dgated is not None:
+            g = g + dgated * gate
+        if dscat is not None:
+            g = g + dscat
+        out = torch.where((inv_p < 0)[:, :, None], g, torch.zeros_like(g))
+        for inv, dseq, off in ((inv_p, dseq_p, off_p), (inv_q, dseq_q, off_q)):
+            if inv is None:
+                continue
+            d = dseq[:, 1:]
+            if p > 0.0:
+                d = d * self.keep(off, b * k * e, p).reshape(b, k, e)
+            picked = torch.gather(d, 1, inv.clamp_min(0).long()[:, :, None].expand(-1, -1, e))
+            out = out + torch.where((inv >= 0)[:, :, None], picked, torch.zeros_like(picked))
+        return out
+
+    def head_grad(self, a1, c1, a2, c2):
+        return (a1 + c1).sum(0).reshape(1, 1, -1), (a2 + c2).sum(0).reshape(1, 1, -1)
+
+    def add3(self, a, b, c):
+        return (a + b) + c
+
     # ------------------------------------------------------------------ K8/K10
     def upsample_softmax(self, logit, c, scale):
         up = F.interpolate(_ncdhw(logit[..., :c]), scale_factor=scale, mode="trilinear", align_corners=False)
@@ -323,10 +555,10 @@ class EmulBackend:
             p_.addcdiv_(m_, denom, value=-step_size)
 
     def dropout_mask(self, shape, p, device, p2=0.0):
-        m = (torch.rand(shape, device=device) >= p).float() * (1.0 / (1.0 - p))
-        if p2 > 0.0:
-            m = m * ((torch.rand(shape, device=device) >= p2).float() * (1.0 / (1.0 - p2)))
-        return m
+        n = 1
+        for d in shape:
+            n *= d
+        return self.keep(self.rng_site(n), n, p, p2).reshape(shape)
 
     def mul(self, a, b):
         return a * b

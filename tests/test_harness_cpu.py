@@ -82,3 +82,42 @@ def test_flip_tta_equals_reference_formula():
         got = po.flip_tta(x, None, fwd, batch=batch)
         assert float((got - want).abs().max()) < 1e-6
     assert float((po.flip_tta(x, None, fwd, resoftmax=False) - want).abs().max()) > 1e-3
+
+
+def test_fused_adam_state_reload_cpu(emul_backend):
+    """FusedAdam (pointer-table launch through the kernel emulation) == torch.optim.Adam(amsgrad, weight_decay) over a
+    save / load_state_dict / continue cycle: 'optim_dict' (train_no_amp.py:252) is interchangeable in both directions."""
+    import copy
+    from cwf.optim import FusedAdam
+    gen = torch.Generator().manual_seed(3)
+    p0 = [torch.randn(300, generator=gen), torch.randn(7, 5, generator=gen)]
+    grads = [[torch.randn(300, generator=gen), torch.randn(7, 5, generator=gen)] for _ in range(6)]
+    ref = [torch.nn.Parameter(t.clone()) for t in p0]
+    ropt = torch.optim.Adam(ref, lr=1e-2, weight_decay=1e-3, amsgrad=True)
+    ours = [torch.nn.Parameter(t.clone()) for t in p0]
+    opt = FusedAdam(ours, lr=1e-2, weight_decay=1e-3, amsgrad=True)
+    for i in range(6):
+        for p, g in zip(ref, grads[i]):
+            p.grad = g.clone()
+        ropt.step()
+        if i == 3:                                   # torch state -> FusedAdam (and our own state_dict round trip)
+            opt = FusedAdam(ours, lr=1e-2, weight_decay=1e-3, amsgrad=True)
+            opt.load_state_dict(copy.deepcopy(ropt.state_dict()))   # (torch shares the 'step' tensor otherwise)
+            for p, r in zip(ours, ref):
+                p.data.copy_(r.data)
+            assert opt._steps == 4
+            continue
+        for p, g in zip(ours, grads[i]):
+            p.grad = g.clone()
+        opt.step()
+        if i == 1:
+            sd = opt.state_dict()
+            opt = FusedAdam(ours, lr=1e-2, weight_decay=1e-3, amsgrad=True)
+            opt.load_state_dict(sd)
+            assert opt._steps == 2
+    for p, r in zip(ours, ref):
+        assert torch.allclose(p, r, rtol=1e-5, atol=1e-7)
+    # and the other direction: torch.optim.Adam accepts our state
+    t2 = torch.optim.Adam(ours, lr=1e-2, weight_decay=1e-3, amsgrad=True)
+    t2.load_state_dict(opt.state_dict())
+    assert float(t2.state[ours[0]]["step"]) == 6.0

@@ -113,10 +113,12 @@ def test_non_cubic_patch_matches_oracle(emul_backend):
     oracle is this repo's own generalisation (sizes derived from the input, multiples of 16) -- parity UNPINNED against the
     reference for such shapes; this checks that the package's module tree agrees with that oracle on a non-cubic patch."""
     m = _model().eval()
-    x, _, _ = syn.synthetic_batch([1], (32, 64, 48))
+    x, _, _ = syn.synthetic_batch([1], (64, 96, 64))
     with torch.no_grad():
         ref = rm.forward(syn.det_state_dict(rm.param_shapes()), x)
         out = m(x, None)
-    assert out[0].shape == (1, 4, 32, 64, 48)
+    assert out[0].shape == (1, 4, 64, 96, 64)
     assert float((out[0] - ref[0]).abs().max()) < 1e-5
     assert float((out[1]["01"] - ref[1]["01"]).abs().max()) < 1e-5 and float((out[2]["04"] - ref[2]["04"]).abs().max()) < 1e-5
+    with pytest.raises(ValueError):          # fewer than 128 semantic tokens: rejected, not silently truncated
+        m(torch.zeros(1, 4, 32, 64, 48), None)

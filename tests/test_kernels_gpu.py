@@ -371,6 +371,54 @@ def test_fused_adam_against_torch_fixture(hip):
     assert set(sd["state"][0].keys()) >= {"step", "exp_avg", "exp_avg_sq", "max_exp_avg_sq"}
 
 
+def test_fused_adam_unsynced_steps_and_state_reload(hip):
+    """(a) 40 optimizer steps enqueued back to back with NO host sync, the learning rate changing every step (poly schedule):
+    the result must equal torch.optim.Adam's -- lr / bias corrections travel as kernel arguments, so a host that runs ahead
+    of the GPU cannot corrupt a step still in flight.  (b) state_dict -> fresh FusedAdam.load_state_dict -> more steps equals
+    the uninterrupted torch run (the descriptor table is rebuilt over the loaded moments, the step counter continues)."""
+    from cwf.optim import FusedAdam, poly_lr
+    gen = torch.Generator().manual_seed(11)
+    shapes = [(1 << 20,), (513, 7), (5,)]
+    p0 = [torch.randn(s, generator=gen) for s in shapes]
+    grads = [[torch.randn(s, generator=gen) * (0.1 + 0.05 * i) for s in shapes] for i in range(60)]
+    ref = [torch.nn.Parameter(t.clone()) for t in p0]
+    ropt = torch.optim.Adam(ref, lr=2e-4, weight_decay=1e-5, amsgrad=True)
+    for i in range(60):
+        ropt.param_groups[0]["lr"] = float(poly_lr(2e-4, i, 100))
+        for p, g in zip(ref, grads[i]):
+            p.grad = g.clone()
+        ropt.step()
+        if i == 39:
+            ref40 = [p.detach().clone() for p in ref]
+    ours = [torch.nn.Parameter(t.clone().to(DEV)) for t in p0]
+    dg = [[g.to(DEV) for g in gs] for gs in grads]
+    opt = FusedAdam(ours, lr=2e-4, weight_decay=1e-5, amsgrad=True)
+    torch.cuda.synchronize()
+    for i in range(40):                                           # no sync inside
+        opt.param_groups[0]["lr"] = float(poly_lr(2e-4, i, 100))
+        for p, g in zip(ours, dg[i]):
+            p.grad = g
+        opt.step()
+    torch.cuda.synchronize()
+    for p, r in zip(ours, ref40):
+        close(p, r, rtol=2e-6, atol=2e-7, what="40 unsynced steps")
+    import copy
+    sd = copy.deepcopy(opt.state_dict())           # (a live state_dict shares its 'step' tensors with the optimizer)
+    opt2 = FusedAdam(ours, lr=2e-4, weight_decay=1e-5, amsgrad=True)
+    opt2.load_state_dict(copy.deepcopy(sd))
+    assert opt2._steps == 40
+    for i in range(40, 60):
+        opt2.param_groups[0]["lr"] = float(poly_lr(2e-4, i, 100))
+        for p, g in zip(ours, dg[i]):
+            p.grad = g
+        opt2.step()
+    for p, r in zip(ours, ref):
+        close(p, r, rtol=3e-6, atol=3e-7, what="resume after load_state_dict")
+    # loading AFTER the first step of an optimizer must also retarget the kernel at the new moment tensors
+    opt2.load_state_dict(copy.deepcopy(sd))
+    assert opt2._steps == 40 and opt2._table is None
+
+
 def test_dropout_mask_kernel(hip):
     """K12 fused keep-mask: values in {0, 1/(1-p)}, drop rate ~ p, independent second mask, reproducible per (seed, counter)."""
     torch.manual_seed(123)
