@@ -2,7 +2,8 @@
 
 One "step" = forward + 5 losses + backward + Adam(amsgrad) on a rank-local batch of 2 synthetic 4-modality 128^3
 volumes (BASELINE.json configs[1]; for N > 1 the same per-rank batch = weak scaling, gradients averaged over ranks by
-bucketed RCCL all-reduce overlapped with backward).  Inputs are resident in HBM before the timed region.
+cwf.trainer.Trainer's RCCL all-reduce of the flat gradient buffer, see its docstring for what overlaps with backward).
+Inputs are resident in HBM before the timed region.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -11,6 +12,9 @@ Rank 0 prints ONE JSON line with the contract fields plus
   roofline     -- the dominant kernel (3x3x3 conv 16->16 @128^3, cwf_conv_mfma): algorithmic FLOPs per launch / average
                   launch duration measured here with HIP events on the launch stream, against the dense fp32 MFMA peak
   cpu_baseline -- the CPU oracle (oracle/reference_model.py, kind "port") timed on this box's host cores, B=1 128^3.
+  val_dice / max_rel_logit_err -- the other half of BASELINE.json's metric: WT/TC/ET Dice (tools.softmax_output_dice,
+                  reference utils/tools.py:89-109) of the HIP model's argmax map against the CPU oracle's argmax map, and the
+                  largest logit deviation relative to the largest |logit|, on the cpu_baseline sample (same weights, eval mode).
 """
 import argparse
 import json
@@ -49,9 +53,22 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-# HBM bytes per launch of the dominant kernel measured with rocprofv3 --pmc (FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE),
-# profiles/round1_conv16_wgrad16_final_pmc.txt (conv16s, sliding window): 2 x 153.8 MB + 269.5 MB.  Re-measure when the kernel changes.
-MEASURED_HBM_BYTES_CONV16 = {"bf16x3": 577.0e6, "bf16": None, "fp32": None}
+# HBM bytes per launch of the dominant kernel come from the committed rocprofv3 --pmc summary (FETCH_SIZE x2 [gfx950 correction]
+# + WRITE_SIZE), not from a constant in this file: profiles/dominant_kernel_traffic.json names the kernel build it was measured
+# on (source hash of conv_bf16.hip); a stale or missing entry yields traffic = null.
+TRAFFIC_FILE = os.path.join(REPO, "profiles", "dominant_kernel_traffic.json")
+
+
+def measured_traffic(precision):
+    import hashlib
+    try:
+        rec = json.load(open(TRAFFIC_FILE))[precision]
+        src = open(os.path.join(PKG, "csrc", "conv_bf16.hip"), "rb").read()
+        if rec.get("conv_bf16_sha16") != hashlib.sha256(src).hexdigest()[:16]:
+            return None, "stale: %s was measured on another build of conv_bf16.hip" % rec.get("source")
+        return float(rec["hbm_bytes_per_launch"]), rec.get("source")
+    except Exception as e:          # missing file / precision: report null rather than a guess
+        return None, "no committed PMC summary (%s)" % type(e).__name__
 MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0 / 3.0, "bf16": 2500.0}   # dense peaks; bf16x3 issues 3 MFMAs per product
 
 
@@ -96,13 +113,39 @@ def dominant_kernel_roofline(dev, precision, iters=20):
     else:
         out = {"kernel": "conv16s_kernel<%s> (v_mfma_f32_16x16x32_bf16, fp32 storage) 3x3x3 16->16 @128^3 x2" % precision, "bound": "hbm",
                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
-    out.update({"traffic": MEASURED_HBM_BYTES_CONV16.get(precision), "avg_launch_ms": round(ms, 4),
+    traffic, traffic_src = measured_traffic(precision)
+    out.update({"traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": flops,
                 "algorithmic_tflops": round(tflops, 2), "frac_of_mfma_peak_for_mode": round(tflops / MFMA_PEAK_TFLOPS[precision], 4)})
     return out
 
 
-def cpu_baseline(steps=2):
+def val_dice_vs_cpu(dev, state, x, precision):
+    """GPU argmax vs CPU-oracle argmax on identical inputs and weights (eval mode, stem dropout off)."""
+    from oracle import reference_model as rm
+    from models.clswiseformer.cls_wise_former import get_cls_wise_former
+    from utils import tools
+    m = get_cls_wise_former(dataset="brats", _conv_repr=True, _pe_type="fixed")
+    m.load_state_dict(state, strict=False)
+    m.Unet_list.InitConv.dropout = 0.0
+    m = m.to(dev).eval()
+    m.collect_aux = True
+    with torch.no_grad():
+        t0 = time.time()
+        ref, aux = rm.forward(state, x, return_aux=True)
+        cpu_fwd = time.time() - t0
+        out = m(x.to(dev), None)
+        seg_gpu = out[0].argmax(1).cpu()
+        logits = m.aux["logits"].float().cpu()
+    seg_cpu = ref[0].argmax(1)
+    dice = [float(d) for d in tools.softmax_output_dice(seg_gpu.numpy(), seg_cpu.numpy())]
+    rel = float((logits - aux["logits"]).abs().max() / aux["logits"].abs().max())
+    return {"WT": round(dice[0], 6), "TC": round(dice[1], 6), "ET": round(dice[2], 6),
+            "argmax_mismatch_voxels": int((seg_gpu != seg_cpu).sum()), "voxels": int(seg_cpu.numel()),
+            "sample": "B=1 4x128^3 synthetic volume, generator-defined weights, eval mode, %s vs fp32 CPU oracle" % precision}, rel, cpu_fwd
+
+
+def cpu_baseline(steps=3, dev=None, precision="bf16x3"):
     """The reference train step (fwd + 5 losses + bwd + Adam amsgrad) as restated in oracle/reference_model.py, on the host
     cores of this box: B=1, 128^3, fp32, 1 warm-up + `steps` timed steps (bounded sample of the same workload)."""
     from oracle import reference_model as rm
@@ -111,8 +154,12 @@ def cpu_baseline(steps=2):
     torch.set_num_threads(cores)
     log("cpu_baseline: %d host threads" % cores)
     state = syn.det_state_dict(rm.param_shapes())
-    tr = rm.CpuTrainer(state)
     x, target, edge = syn.synthetic_batch([0], (128, 128, 128))
+    extra = {}
+    if dev is not None:
+        extra["val_dice"], extra["max_rel_logit_err"], fwd_s = val_dice_vs_cpu(dev, state, x, precision)
+        log("val_dice leg done (CPU oracle forward %.1f s): %s, max rel logit err %.2e" % (fwd_s, extra["val_dice"], extra["max_rel_logit_err"]))
+    tr = rm.CpuTrainer(state)
     t0 = time.time()
     tr.step(x, target, edge)
     log("cpu_baseline: warm-up step %.1f s" % (time.time() - t0))
@@ -123,7 +170,7 @@ def cpu_baseline(steps=2):
     dt = (time.time() - t0) / steps
     return {"value": round(1.0 / dt, 4), "unit": "volumes/s", "cores": cores, "kind": "port",
             "sample": "%d timed steps (+1 warm-up) of B=1 4x128^3 fwd+5 losses+bwd+Adam(amsgrad), fp32, torch CPU ops" % steps,
-            "sec_per_step": round(dt, 3)}
+            "sec_per_step": round(dt, 3)}, extra
 
 
 def main():
@@ -134,7 +181,7 @@ def main():
     ap.add_argument("--batch", type=int, default=2, help="rank-local batch (independent B=1 samples, SURVEY F2)")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph of fwd+bwd instead of launching every kernel from "
                     "Python (host cost 1 ms instead of ~26 ms per step; currently slower end to end: the three sub-region streams "
                     "overlap in eager mode but a captured graph serialises more)")
@@ -220,7 +267,8 @@ def main():
         out["roofline"] = dominant_kernel_roofline(dev, args.precision)
         log("roofline leg done: %s" % json.dumps(out["roofline"]))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
+            out["cpu_baseline"], extra = cpu_baseline(args.cpu_steps, dev, args.precision)
+            out.update(extra)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

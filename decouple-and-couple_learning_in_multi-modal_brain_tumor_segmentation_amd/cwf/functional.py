@@ -99,7 +99,7 @@ class WeightPacker:
 # ======================================================================================================
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, spec, in_scale, in_shift, slope, residual, out_scale, want_stats):
+    def forward(ctx, x, w, b, spec, in_scale, in_shift, slope, residual, out_scale, want_stats, carry):
         K = backend()
         n = x.shape[0]
         spec.uses += 1
@@ -109,14 +109,19 @@ class _ConvFn(torch.autograd.Function):
         ctx.spec, ctx.slope = spec, slope
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, w, in_scale, in_shift, out_scale)
+        # carry: x is handed on as a second output (an alias).  Whatever consumes that alias (a residual connection, a skip
+        # connection) sends its gradient back HERE, where it is folded into the kernel that writes dx (dx_add of the
+        # InstanceNorm-backward apply, or the residual operand of the data-gradient conv) instead of autograd summing the
+        # two gradients of x with a separate full-resolution add launch.
+        xc = x if carry else None
         if want_stats:
             sc, sh = K.in_finalize(stats, y.shape[1] * y.shape[2] * y.shape[3])
             ctx.mark_non_differentiable(sc, sh)
-            return y, sc, sh
-        return y, None, None
+            return y, sc, sh, xc
+        return y, None, None, xc
 
     @staticmethod
-    def backward(ctx, dy, _a, _b):
+    def backward(ctx, dy, _a, _b, dcarry):
         K = backend()
         x, w, in_scale, in_shift, out_scale = ctx.saved_tensors
         spec = ctx.spec
@@ -144,19 +149,25 @@ class _ConvFn(torch.autograd.Function):
                 sums = K.new_stats(x.shape[0], spec.cin, x.device)
                 K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op,
                        stats=sums, nb=(x, in_scale, in_shift, ctx.slope))
-                dx = K.in_bwd_apply(dxa, x, in_scale, in_shift, ctx.slope, sums)
-            else:
+                dx = K.in_bwd_apply(dxa, x, in_scale, in_shift, ctx.slope, sums, dx_add=dcarry)
+            elif in_scale is not None:
                 K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op)
-                dx = K.in_bwd(dxa, x, in_scale, in_shift, ctx.slope) if in_scale is not None else dxa
-        return dx, dw, db, None, None, None, None, dres, None, None
+                dx = K.in_bwd(dxa, x, in_scale, in_shift, ctx.slope, dx_add=dcarry)
+            else:
+                dx = K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op, residual=dcarry)
+        elif dcarry is not None:
+            dx = dcarry
+        return dx, dw, db, None, None, None, None, dres, None, None, None
 
 
-def conv(x, w, b, spec, in_norm=None, slope=1.0, residual=None, out_scale=None, want_stats=False):
+def conv(x, w, b, spec, in_norm=None, slope=1.0, residual=None, out_scale=None, want_stats=False, carry=False):
     """y = conv(act(IN(x)))(+bias)(+residual)(*out_scale).  in_norm = (scale, shift) of x or None.
-    Returns (y, (scale_y, shift_y) or None)."""
+    Returns (y, (scale_y, shift_y) or None), with carry=True (y, stats, x_alias): use x_alias for every further use of x
+    (see _ConvFn.forward)."""
     sc, sh = in_norm if in_norm is not None else (None, None)
-    y, s1, s2 = _ConvFn.apply(x, w, b, spec, sc, sh, float(slope), residual, out_scale, want_stats)
-    return y, ((s1, s2) if want_stats else None)
+    y, s1, s2, xc = _ConvFn.apply(x, w, b, spec, sc, sh, float(slope), residual, out_scale, want_stats, carry)
+    st = (s1, s2) if want_stats else None
+    return (y, st, xc) if carry else (y, st)
 
 
 class _NormActAddFn(torch.autograd.Function):

@@ -72,7 +72,6 @@ class HipBackend:
         self._ws = {}
         self._arena = {}
         self._arena_off = {}
-        self._rng_counter = 0
         self._rng = {}                         # device -> int64[2] {seed, step} (device-resident generator state)
         self._rng_seed = {}
         self._site = 0                         # per-step dropout-site offset (reset by begin_step, static across steps)
@@ -94,7 +93,8 @@ class HipBackend:
 
     def workspace(self, key, nfloats, device):
         """Grow-only scratch buffers (wgrad partial slabs), one per (device, stream): reuse is stream-ordered."""
-        k = (key, device, _raw_stream(_current_device()))
+        # (buffers allocated while capturing live in the graph's private pool: keep them apart from the eager ones)
+        k = (key, device, _raw_stream(_current_device()), torch.cuda.is_current_stream_capturing())
         buf = self._ws.get(k)
         if buf is None or buf.numel() < nfloats:
             buf = torch.empty(int(nfloats), dtype=_f32, device=device)
@@ -222,7 +222,9 @@ class HipBackend:
             torch.cuda.current_stream(st.device).wait_stream(st)
 
     def wgrad(self, op, x, in_scale, in_shift, slope, dy, cout, inv_map, has_bias_map, w_numel, w_ref_shape=None, prec=None, allow_async=False):
-        if self.wgrad_async and allow_async and not torch.cuda.is_current_stream_capturing():
+        if self.wgrad_async and allow_async:
+            # also under hipGraph capture: the side stream joins the capture through wait_stream and becomes a parallel branch of
+            # the graph; record_stream defers the operands' blocks until the capture ends (no reuse inside the graph)
             side = self.wgrad_stream(x.device)
             side.wait_stream(torch.cuda.current_stream(x.device))
             with torch.cuda.stream(side):

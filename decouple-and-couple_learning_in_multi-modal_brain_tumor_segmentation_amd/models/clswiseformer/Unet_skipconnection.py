@@ -7,6 +7,7 @@ All activations are [N, D, H, W, C]."""
 import torch
 import torch.nn as nn
 
+from cwf import functional as CF
 from .layers import HipConv
 
 
@@ -22,7 +23,7 @@ class InitConv(nn.Module):
     def forward(self, x, keep=None):
         if keep is None and self.dropout > 0.0:
             p = self.dropout
-            keep = (torch.rand((x.shape[0], self.conv.spec.cout), device=x.device) >= p).float() * (1.0 / (1.0 - p))
+            keep = CF.dropout_mask((x.shape[0], self.conv.spec.cout), p, x.device)      # HIP kernel over the device generator state
         return self.conv(x, out_scale=keep, want_stats=True)
 
 
@@ -35,8 +36,9 @@ class EnBlock(nn.Module):
         self.conv2 = HipConv(in_channels, in_channels)
 
     def forward(self, x, x_stats, want_stats=True):
-        h, hs = self.conv1(x, in_norm=x_stats, slope=0.0, want_stats=True)
-        return self.conv2(h, in_norm=hs, slope=0.0, residual=x, want_stats=want_stats)
+        # carry: the residual's gradient returns to conv1's backward and is added inside the kernel that writes dx
+        h, hs, xc = self.conv1(x, in_norm=x_stats, slope=0.0, want_stats=True, carry=True)
+        return self.conv2(h, in_norm=hs, slope=0.0, residual=xc, want_stats=want_stats)
 
 
 class EnDown(nn.Module):
@@ -44,8 +46,8 @@ class EnDown(nn.Module):
         super().__init__()
         self.conv = HipConv(in_channels, out_channels, stride=stride)
 
-    def forward(self, x, want_stats=True):
-        return self.conv(x, want_stats=want_stats)
+    def forward(self, x, want_stats=True, carry=False):
+        return self.conv(x, want_stats=want_stats, carry=carry)
 
 
 class Unet(nn.Module):
@@ -70,13 +72,14 @@ class Unet(nn.Module):
         x, s = self.InitConv(x, stem_keep)
         x, s = self.EnBlock1(x, s)
         x1, _ = self.EnBlock1_1(x, s, want_stats=False)
-        x, s = self.EnDown1(x1)
+        # the skip connections leave through the carry alias of the down-sampling conv (their gradient is folded into its dgrad)
+        x, s, x1 = self.EnDown1(x1, carry=True)
         x, s = self.EnBlock2_1(x, s)
         x2, _ = self.EnBlock2_2(x, s, want_stats=False)
-        x, s = self.EnDown2(x2)
+        x, s, x2 = self.EnDown2(x2, carry=True)
         x, s = self.EnBlock3_1(x, s)
         x3, _ = self.EnBlock3_2(x, s, want_stats=False)
-        x, s = self.EnDown3(x3)
+        x, s, x3 = self.EnDown3(x3, carry=True)
         x, s = self.EnBlock4_1(x, s)
         x, _ = self.EnBlock4_2(x, s, want_stats=False)
         x4, _ = self.EnDown_4(x, want_stats=False)

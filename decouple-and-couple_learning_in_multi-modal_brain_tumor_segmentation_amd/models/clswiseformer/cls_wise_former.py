@@ -117,7 +117,7 @@ class ClsWiseFormer(nn.Module):
 
     def encode(self, x, missing_modal=None):
         x1, x2, x3, x4 = self.Unet_list(x)
-        x2d, _ = self.conv_64_to_32(x2)                           # :284
+        x2d, _, x2 = self.conv_64_to_32(x2, carry=True)           # :284 (x2 goes on to the decoder through the carry alias)
         x23 = CF.cat_channels(x2d, x3)
 
         # The three sub-region pipelines are made of small, latency-bound kernels (16^3 / 32^3 grids, 129-token GEMMs):
@@ -194,9 +194,9 @@ class EnBlock2(nn.Module):
         self.conv2 = HipConv(in_channels, in_channels)
 
     def forward(self, x):
-        h, hs = self.conv1(x, want_stats=True)
+        h, hs, xc = self.conv1(x, want_stats=True, carry=True)        # the residual's gradient is folded into conv1's dgrad epilogue
         g, gs = self.conv2(h, in_norm=hs, slope=0.01, want_stats=True)
-        return CF.norm_act_add(g, gs, 0.01, residual=x)
+        return CF.norm_act_add(g, gs, 0.01, residual=xc)
 
 
 class DeBlock(EnBlock2):

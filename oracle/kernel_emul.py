@@ -129,7 +129,7 @@ class EmulBackend:
         with torch.enable_grad():
             y = _fwd_conv(fwd_op, xin, w_ref, None)
             (g,) = torch.autograd.grad(y, xin, dy.contiguous())
-        out.copy_(g)
+        out.copy_(g + residual if residual is not None else g)
         return out
 
     def wgrad(self, op, x, in_scale, in_shift, slope, dy, cout, inv_map, has_bias_map, w_numel, w_ref_shape=None, prec=None, allow_async=False):

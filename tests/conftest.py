@@ -33,4 +33,4 @@ def hip():
     from cwf import kernels
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     kernels._set_backend_for_testing(None)
-    return kernels.backend()
+    return kernels.backend()          # the product backend instance (kernels.backend() keeps returning this object)

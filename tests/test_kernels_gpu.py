@@ -420,9 +420,9 @@ def test_fused_adam_unsynced_steps_and_state_reload(hip):
 
 
 def test_dropout_mask_kernel(hip):
-    """K12 fused keep-mask: values in {0, 1/(1-p)}, drop rate ~ p, independent second mask, reproducible per (seed, counter)."""
+    """K12 fused keep-mask: values in {0, 1/(1-p)}, drop rate ~ p, independent second mask, reproducible per (seed, step, site offset) of the device generator state."""
     torch.manual_seed(123)
-    hip._rng_counter = 0
+    hip._site = 0
     m = hip.dropout_mask((4, 8, 129, 129), 0.1, DEV).cpu()
     vals = torch.unique(m)
     assert len(vals) == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1 / 0.9) < 1e-6
@@ -430,7 +430,7 @@ def test_dropout_mask_kernel(hip):
     m2 = hip.dropout_mask((4, 8, 129, 129), 0.1, DEV, p2=0.2).cpu()
     assert abs(float((m2 == 0).float().mean()) - (1 - 0.9 * 0.8)) < 5e-3 and abs(float(m2.mean()) - 1.0) < 1e-2
     assert not torch.equal(m != 0, m2 != 0)
-    hip._rng_counter = 0
+    hip._site = 0                      # same (seed, step, site offset) -> same mask
     assert torch.equal(hip.dropout_mask((4, 8, 129, 129), 0.1, DEV).cpu(), m)
     # neighbouring elements are uncorrelated (lag-1 autocorrelation of the keep bits)
     k = (m.reshape(-1) != 0).float(); k = k - k.mean()

@@ -260,3 +260,67 @@ def test_wgrad_side_stream_gives_same_gradients(hip):
     diff = float((flats[0] - flats[1]).norm() / flats[0].norm())           # sync vs side stream
     assert float(flats[0].abs().sum()) > 0 and bool(torch.isfinite(flats[1]).all())
     assert diff < max(5e-5, 10 * noise), (diff, noise)
+
+
+def _no_dropout_model(forced):
+    m = _model().train()
+    m.forced_index = forced
+    m.Unet_list.InitConv.dropout = 0.0
+    for mod in m.modules():
+        if hasattr(mod, "dropout_rate"):
+            mod.dropout_rate = 0.0
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    return m
+
+
+def test_graph_replay_matches_eager_step(hip):
+    """Trainer(use_graph=True): forward + 5 losses + backward + gradient flattening captured into ONE hipGraph -- including the three
+    region streams and the side-stream weight gradients as parallel branches -- must give the eager step's flat gradient
+    (teacher-forced top-k, dropout off: what remains is float-atomic reduction-order noise, measured eager vs eager), on the
+    capture's own inputs and on NEW inputs copied into the static buffers; with dropout ON, two replays must draw different masks
+    (the generator state is advanced by a captured kernel)."""
+    from cwf import kernels
+    from cwf.trainer import Trainer
+    kernels.set_precision("bf16x3")
+    try:
+        xs, ts, es = zip(*[syn.synthetic_batch([i], (64, 64, 64)) for i in (0, 5)])
+        with torch.no_grad():
+            _, aux = rm.forward(syn.det_state_dict(rm.param_shapes()), xs[0], return_aux=True)
+        forced = {k: v.to(DEV) for k, v in aux.items() if v.dtype == torch.int64}
+        dev = lambda i: (xs[i].to(DEV), ts[i].to(DEV), es[i].to(DEV))
+        eager = []
+        for rep in range(2):
+            tr = Trainer(_no_dropout_model(forced))
+            per = []
+            for i in (0, 1):
+                tr._fwd_bwd(*dev(i))
+                torch.cuda.synchronize()
+                per.append(tr.opt.flat_grad.clone())
+            eager.append(per)
+        noise = max(float((eager[0][i] - eager[1][i]).norm() / eager[0][i].norm()) for i in (0, 1))
+        trg = Trainer(_no_dropout_model(forced), use_graph=True)
+        assert trg.wgrad_async
+        trg._fwd_bwd(*dev(0))                               # eager warm-up (allocations, weight-pack tables)
+        torch.cuda.synchronize()
+        trg._capture(*dev(0))
+        for i in (0, 1, 0):
+            for dst, src in zip(trg._static, dev(i)):
+                dst.copy_(src)
+            trg._graph.replay()
+            torch.cuda.synchronize()
+            g = trg.opt.flat_grad
+            assert bool(torch.isfinite(g).all()) and float(g.abs().sum()) > 0
+            diff = float((g - eager[0][i]).norm() / eager[0][i].norm())
+            assert diff < max(5e-5, 10 * noise), (i, diff, noise)
+        # dropout on: replays differ (fresh masks), and stay finite
+        m = _model().train()
+        trd = Trainer(m, use_graph=True)
+        trd._fwd_bwd(*dev(0)); torch.cuda.synchronize()
+        trd._capture(*dev(0))
+        trd._graph.replay(); torch.cuda.synchronize(); g1 = trd.opt.flat_grad.clone()
+        trd._graph.replay(); torch.cuda.synchronize(); g2 = trd.opt.flat_grad.clone()
+        assert bool(torch.isfinite(g1).all()) and bool(torch.isfinite(g2).all())
+        assert float((g1 - g2).norm() / g1.norm()) > 1e-3
+    finally:
+        kernels.set_precision("fp32")
