@@ -15,18 +15,13 @@ __device__ __forceinline__ void src_index(int dst, float inv_scale, int in, int&
   l1 = s - (float)i0;
 }
 
+// softmax over C channels of the trilinear interpolation of `logit` at high-resolution voxel (od, oh, ow) of sample n.
+// One definition for the map-writing kernel and the fused head -> loss kernels: identical arithmetic, identical probabilities.
 template <int C>
-__global__ void upsample_softmax_kernel(const float* __restrict__ logit, int l_ldc, float* __restrict__ prob,
-                                        int D, int H, int W, int scale, int64_t total) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // over output voxels
-  if (idx >= total) return;
-  const int Wo = W * scale, Ho = H * scale, Do = D * scale;
-  int64_t v = idx;
-  const int ow = (int)(v % Wo); v /= Wo; const int oh = (int)(v % Ho); v /= Ho; const int od = (int)(v % Do); const int n = (int)(v / Do);
-  const float inv = 1.0f / (float)scale;
+__device__ __forceinline__ void upsample_softmax_at(const float* __restrict__ logit, int l_ldc, int n, int D, int H, int W,
+                                                    int od, int oh, int ow, float inv, float* val) {
   int d0, d1, h0, h1, w0, w1; float ld, lh, lw;
   src_index(od, inv, D, d0, d1, ld); src_index(oh, inv, H, h0, h1, lh); src_index(ow, inv, W, w0, w1, lw);
-  float val[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) val[c] = 0.f;
   const float wd[2] = {1.f - ld, ld}, wh[2] = {1.f - lh, lh}, ww[2] = {1.f - lw, lw};
@@ -50,7 +45,21 @@ __global__ void upsample_softmax_kernel(const float* __restrict__ logit, int l_l
   for (int c = 0; c < C; ++c) { val[c] = expf(val[c] - mx); sum += val[c]; }
   const float r = 1.f / sum;
 #pragma unroll
-  for (int c = 0; c < C; ++c) prob[idx * C + c] = val[c] * r;
+  for (int c = 0; c < C; ++c) val[c] *= r;
+}
+
+template <int C>
+__global__ void upsample_softmax_kernel(const float* __restrict__ logit, int l_ldc, float* __restrict__ prob,
+                                        int D, int H, int W, int scale, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // over output voxels
+  if (idx >= total) return;
+  const int Wo = W * scale, Ho = H * scale, Do = D * scale;
+  int64_t v = idx;
+  const int ow = (int)(v % Wo); v /= Wo; const int oh = (int)(v % Ho); v /= Ho; const int od = (int)(v % Do); const int n = (int)(v / Do);
+  float val[C];
+  upsample_softmax_at<C>(logit, l_ldc, n, D, H, W, od, oh, ow, 1.0f / (float)scale, val);
+#pragma unroll
+  for (int c = 0; c < C; ++c) prob[idx * C + c] = val[c];
 }
 
 // Adjoint of upsample + softmax, separable and deterministic (no atomics), two launches:
@@ -204,6 +213,176 @@ extern "C" int cwf_channel_softmax_bwd(const float* dprob, const float* prob, fl
   if (C == 2) hipLaunchKernelGGL(channel_softmax_bwd_kernel<2>, grid, dim3(256), 0, cwf_stream(stream), dprob, prob, dlogit, dl_ldc, nvox);
   else if (C == 4) hipLaunchKernelGGL(channel_softmax_bwd_kernel<4>, grid, dim3(256), 0, cwf_stream(stream), dprob, prob, dlogit, dl_ldc, nvox);
   else return CWF_E_BADARG;
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+
+// =====================================================================================================================
+// Fused head -> loss (training): the per-sub-region Dice / weighted-CE sums straight from the LOW-resolution logits.
+//   reference: SuperviseLabel.py:58-81 / EdgeSuperviseLabel.py:56-76 (conv -> conv -> trilinear -> softmax) feeding
+//   tools.get_separate_loss / get_edge_separate_loss (tools.py:112-231 -> dice_loss :8-18 + softmax_weighted_loss :21-34).
+// The unfused path writes each [N,2,D,H,W] probability map (upsample_softmax), re-reads it for the sums, re-reads it for
+// dLoss/dprob, writes dprob and re-reads both in the interpolation adjoint: ~6 full-resolution passes per map, 12 maps per step.
+// Here the upsample + softmax is evaluated in registers where it is needed (the 16^3 / 32^3 logits stay in L1/L2), the three
+// maps of one supervision call share ONE read of the label volume, and nothing is written at full resolution.
+//   forward : sums[m][n][c][4] += (sum p t, sum p, sum t, sum t log clamp(p, 0.005, 1))     (f64 atomics per block, zeroed by caller)
+//   backward: ws[m][n][od][jh][jw][c] = sum_oh fh sum_ow fw p_c (g_c - sum_k p_k g_k), g = dLoss/dp from (label, coef);
+//             then the planes pass finishes along D and writes dlogit (pad channels zeroed)
+// =====================================================================================================================
+struct HeadLossArgs {
+  const float* logit[3]; uint32_t posmask[3]; int l_ldc; const int64_t* label; double* sums; const float* coef; const float* gscale;
+  float* ws; int N, D, H, W, scale, nm; int64_t V; int vox_per_block;
+};
+
+__global__ __launch_bounds__(256) void head_loss_sums_kernel(const HeadLossArgs a) {
+  __shared__ float red[4][3 * 8];
+  const int n = blockIdx.y;
+  const int Wo = a.W * a.scale, Ho = a.H * a.scale;
+  const int64_t v0 = (int64_t)blockIdx.x * a.vox_per_block, v1 = min(a.V, v0 + a.vox_per_block);
+  const float inv = 1.0f / (float)a.scale;
+  float acc[3][2][4];
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { acc[m][c][0] = acc[m][c][1] = acc[m][c][2] = acc[m][c][3] = 0.f; }
+  for (int64_t v = v0 + threadIdx.x; v < v1; v += 256) {
+    const int lab = (int)a.label[(int64_t)n * a.V + v];
+    const int ow = (int)(v % Wo); const int64_t t = v / Wo; const int oh = (int)(t % Ho); const int od = (int)(t / Ho);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      if (m >= a.nm) break;
+      float p[2];
+      upsample_softmax_at<2>(a.logit[m], a.l_ldc, n, a.D, a.H, a.W, od, oh, ow, inv, p);
+      const int cls = (int)((a.posmask[m] >> (lab & 31)) & 1u);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float tt = (cls == c) ? 1.f : 0.f;
+        acc[m][c][0] += p[c] * tt; acc[m][c][1] += p[c]; acc[m][c][2] += tt;
+        acc[m][c][3] += tt * logf(fminf(fmaxf(p[c], 0.005f), 1.0f));
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float s = wave_sum(acc[m][c][k]); if (lane == 0) red[w][m * 8 + c * 4 + k] = s; }
+  __syncthreads();
+  if (threadIdx.x < a.nm * 8) {
+    const int m = threadIdx.x >> 3, ck = threadIdx.x & 7;
+    const double s = (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] + (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x];
+    atomic_add_f64(a.sums + (((int64_t)m * a.N + n) * 2) * 4 + ck, s);
+  }
+}
+
+// one block per (n, od, jh), like upsample_softmax_bwd_rows_kernel; LDS col[nm][Wo][2]
+__global__ void head_loss_bwd_rows_kernel(const HeadLossArgs a) {
+  extern __shared__ float col[];
+  int b = blockIdx.x;
+  const int H = a.H, W = a.W, D = a.D, scale = a.scale;
+  const int jh = b % H; b /= H;
+  const int Do = D * scale, Ho = H * scale, Wo = W * scale;
+  const int od = b % Do; const int n = b / Do;
+  const float inv = 1.0f / (float)scale;
+  const float gs = a.gscale[0];
+  const int oh_lo = max(0, scale * jh - scale / 2), oh_hi = min(Ho, scale * jh + scale + scale / 2);
+  const int64_t* lb = a.label + (((int64_t)n * Do + od) * Ho) * (int64_t)Wo;
+  for (int ow = threadIdx.x; ow < Wo; ow += blockDim.x) {
+    float acc[3][2];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { acc[m][0] = 0.f; acc[m][1] = 0.f; }
+    for (int oh = oh_lo; oh < oh_hi; ++oh) {
+      const float fh = tri_weight(oh, inv, H, jh);
+      const int lab = (int)lb[(int64_t)oh * Wo + ow];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        if (m >= a.nm) break;
+        float p[2], g[2];
+        upsample_softmax_at<2>(a.logit[m], a.l_ldc, n, D, H, W, od, oh, ow, inv, p);
+        const int cls = (int)((a.posmask[m] >> (lab & 31)) & 1u);
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const float* k = a.coef + (((int64_t)m * a.N + n) * 2 + c) * 4;
+          float gg = k[1];
+          if (cls == c) { gg += k[0]; if (p[c] >= 0.005f && p[c] <= 1.0f) gg += k[2] / p[c]; }
+          g[c] = gs * gg; dot += p[c] * g[c];
+        }
+        acc[m][0] += fh * p[0] * (g[0] - dot); acc[m][1] += fh * p[1] * (g[1] - dot);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { if (m < a.nm) { col[(m * Wo + ow) * 2] = acc[m][0]; col[(m * Wo + ow) * 2 + 1] = acc[m][1]; } }
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < a.nm * W * 2; q += blockDim.x) {
+    const int c = q & 1, jw = (q >> 1) % W, m = (q >> 1) / W;
+    const int ow_lo = max(0, scale * jw - scale / 2), ow_hi = min(Wo, scale * jw + scale + scale / 2);
+    float s = 0.f;
+    for (int ow = ow_lo; ow < ow_hi; ++ow) s += tri_weight(ow, inv, W, jw) * col[(m * Wo + ow) * 2 + c];
+    a.ws[(((((int64_t)m * a.N + n) * Do + od) * H + jh) * W + jw) * 2 + c] = s;
+  }
+}
+
+struct HeadPlanesArgs { float* dlogit[3]; const float* ws; int dl_ldc, N, D, H, W, scale, nm; int64_t per_map; };
+// dlogit_m[n][jd][jh][jw][c] = sum_od fd(od, jd) ws[m][n][od][jh][jw][c] for c < 2, ZERO for the pad channels c in [2, dl_ldc)
+__global__ void head_loss_bwd_planes_kernel(const HeadPlanesArgs a) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // over (n, jd, jh, jw, c < dl_ldc)
+  if (idx >= a.per_map) return;
+  const int m = blockIdx.y;
+  int64_t v = idx;
+  const int c = (int)(v % a.dl_ldc); v /= a.dl_ldc;
+  const int64_t hw = v % ((int64_t)a.H * a.W); v /= (int64_t)a.H * a.W;
+  const int jd = (int)(v % a.D); const int n = (int)(v / a.D);
+  float s = 0.f;
+  if (c < 2) {
+    const int Do = a.D * a.scale;
+    const float inv = 1.0f / (float)a.scale;
+    const int od_lo = max(0, a.scale * jd - a.scale / 2), od_hi = min(Do, a.scale * jd + a.scale + a.scale / 2);
+    for (int od = od_lo; od < od_hi; ++od)
+      s += tri_weight(od, inv, a.D, jd) * a.ws[(((((int64_t)m * a.N + n) * Do + od) * a.H * a.W) + hw) * 2 + c];
+  }
+  a.dlogit[m][idx] = s;
+}
+
+extern "C" int cwf_head_loss_sums(const float* const* logits, int nmaps, int l_ldc, const uint32_t* posmasks, const int64_t* label,
+                                  double* sums, int N, int D, int H, int W, int scale, void* stream) {
+  if (!logits || !posmasks || !label || !sums || nmaps <= 0 || nmaps > 3 || N <= 0 || scale <= 0 || l_ldc < 2) return CWF_E_BADARG;
+  HeadLossArgs a = {};
+  for (int m = 0; m < nmaps; ++m) { if (!logits[m]) return CWF_E_BADARG; a.logit[m] = logits[m]; a.posmask[m] = posmasks[m]; }
+  a.l_ldc = l_ldc; a.label = label; a.sums = sums; a.N = N; a.D = D; a.H = H; a.W = W; a.scale = scale; a.nm = nmaps;
+  a.V = (int64_t)D * H * W * scale * scale * scale;
+  int64_t vpb = cdiv64(a.V * N, 2048); if (vpb < 1024) vpb = 1024; if (vpb > a.V) vpb = a.V;
+  a.vox_per_block = (int)vpb;
+  hipLaunchKernelGGL(head_loss_sums_kernel, dim3((unsigned)cdiv64(a.V, vpb), N), dim3(256), 0, cwf_stream(stream), a);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cwf_head_loss_bwd(const float* const* logits, int nmaps, int l_ldc, const uint32_t* posmasks, const int64_t* label,
+                                 const float* coef, const float* gscale, float* const* dlogits, int dl_ldc, float* workspace,
+                                 int N, int D, int H, int W, int scale, void* stream) {
+  if (!logits || !posmasks || !label || !coef || !gscale || !dlogits || !workspace || nmaps <= 0 || nmaps > 3 || N <= 0) return CWF_E_BADARG;
+  if (scale <= 0 || (scale & 1) || l_ldc < 2 || dl_ldc < 2) return CWF_E_BADARG;
+  HeadLossArgs a = {};
+  HeadPlanesArgs pa = {};
+  for (int m = 0; m < nmaps; ++m) {
+    if (!logits[m] || !dlogits[m]) return CWF_E_BADARG;
+    a.logit[m] = logits[m]; a.posmask[m] = posmasks[m]; pa.dlogit[m] = dlogits[m];
+  }
+  a.l_ldc = l_ldc; a.label = label; a.coef = coef; a.gscale = gscale; a.ws = workspace;
+  a.N = N; a.D = D; a.H = H; a.W = W; a.scale = scale; a.nm = nmaps;
+  const int Wo = W * scale;
+  const int threads = Wo >= 256 ? 256 : ((Wo + 63) / 64) * 64;
+  const size_t lds = (size_t)nmaps * Wo * 2 * sizeof(float);
+  if (lds > 64 * 1024) return CWF_E_BADARG;
+  hipStream_t st = cwf_stream(stream);
+  hipLaunchKernelGGL(head_loss_bwd_rows_kernel, dim3((unsigned)((int64_t)N * D * scale * H)), dim3(threads), lds, st, a);
+  pa.ws = workspace; pa.dl_ldc = dl_ldc; pa.N = N; pa.D = D; pa.H = H; pa.W = W; pa.scale = scale; pa.nm = nmaps;
+  pa.per_map = (int64_t)N * D * H * W * dl_ldc;
+  hipLaunchKernelGGL(head_loss_bwd_planes_kernel, dim3((unsigned)cdiv64(pa.per_map, 256), nmaps), dim3(256), 0, st, pa);
   CWF_LAUNCH_CHECK();
   return 0;
 }

@@ -45,8 +45,11 @@ __global__ __launch_bounds__(256) void dice_ce_sums_kernel(const float* __restri
 //   dice = 1 - (1/C) sum_c 2 I_c / (P_c + T_c + 1e-7)          (sums over the whole batch)
 //   ce   = (1/(N V)) sum_n sum_c -w_c[n] S_c[n],  w_c[n] = 1 - T_c[n] / sum_c T_c[n]
 //   coef[n][c] = ( a_c = -(2/C)/den_c , b_c = (2/C) I_c/den_c^2 , k_c[n] = -w_c[n]/(N V) , 0 )
-__global__ void dice_ce_finalize_kernel(const double* __restrict__ sums, float* __restrict__ loss, float* __restrict__ coef, int N, double V, int C) {
+__global__ void dice_ce_finalize_kernel(const double* __restrict__ sums, float* __restrict__ loss, float* __restrict__ coef, int N, double V, int C,
+                                        int nmaps, float* __restrict__ total) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float tot_all = 0.f;                               // fp32, in order: the reference sums the per-region loss tensors (tools.py:160-162)
+  for (int m = 0; m < nmaps; ++m, sums += (int64_t)N * C * 4, coef += (int64_t)N * C * 4, ++loss) {
   double dice = 0.0, ce = 0.0;
   for (int c = 0; c < C; ++c) {
     double I = 0, P = 0, T = 0;
@@ -71,6 +74,9 @@ __global__ void dice_ce_finalize_kernel(const double* __restrict__ sums, float* 
     }
   }
   loss[0] = (float)((1.0 - dice / C) + ce / ((double)N * V));
+  tot_all += loss[0];
+  }
+  if (total) total[0] = tot_all;
 }
 
 template <int C>
@@ -112,7 +118,15 @@ extern "C" int cwf_dice_ce_sums(const float* prob, const int64_t* label, uint32_
 
 extern "C" int cwf_dice_ce_finalize(const double* sums, float* loss, float* coef, int N, int64_t V, int C, void* stream) {
   if (!sums || !loss || !coef || N <= 0 || V <= 0 || (C != 2 && C != 4)) return CWF_E_BADARG;
-  hipLaunchKernelGGL(dice_ce_finalize_kernel, dim3(1), dim3(64), 0, cwf_stream(stream), sums, loss, coef, N, (double)V, C);
+  hipLaunchKernelGGL(dice_ce_finalize_kernel, dim3(1), dim3(64), 0, cwf_stream(stream), sums, loss, coef, N, (double)V, C, 1, (float*)nullptr);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+
+// nmaps problems laid out back to back (sums [nmaps][N][C][4], loss [nmaps], coef [nmaps][N][C][4]) + their sum -> total[0]
+extern "C" int cwf_dice_ce_finalize_multi(const double* sums, float* loss, float* coef, float* total, int nmaps, int N, int64_t V, int C, void* stream) {
+  if (!sums || !loss || !coef || nmaps <= 0 || N <= 0 || V <= 0 || (C != 2 && C != 4)) return CWF_E_BADARG;
+  hipLaunchKernelGGL(dice_ce_finalize_kernel, dim3(1), dim3(64), 0, cwf_stream(stream), sums, loss, coef, N, (double)V, C, nmaps, total);
   CWF_LAUNCH_CHECK();
   return 0;
 }

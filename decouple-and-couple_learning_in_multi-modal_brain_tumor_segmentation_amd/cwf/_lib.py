@@ -77,6 +77,9 @@ SIGNATURES = {
     "cwf_scatter_bwd": [P, P, P, P, P, P, L, L, P, L, P, L, P, L, L, P, L, I, I, I, I, P],
     "cwf_token_grad": [P, P, P, L, P, P, P, L, P, L, P, U64, U64, F, P, I, I, I, I, P],
     "cwf_head_grad": [P, P, P, P, L, P, P, I, I, P],
+    "cwf_dice_ce_finalize_multi": [P, P, P, P, I, I, L, I, P],
+    "cwf_head_loss_sums": [P, I, I, P, P, P, I, I, I, I, I, P],
+    "cwf_head_loss_bwd": [P, I, I, P, P, P, P, P, I, P, I, I, I, I, I, P],
     "cwf_rng_advance": [P, P],
     "cwf_dropout_mask_rng": [P, L, F, F, P, U64, P],
 }

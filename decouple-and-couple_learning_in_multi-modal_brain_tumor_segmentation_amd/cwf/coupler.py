@@ -139,6 +139,7 @@ class RegionCouplerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, E, S, e_tok, s_tok, *P):
         K = backend()
+        ctx.set_materialize_grads(False)     # unused outputs arrive as None in backward, not as zero-filled tensors
         E, S = E.contiguous(), S.contiguous()
         b, _, e = E.shape
         k = min(cfg.k, S.shape[1], E.shape[1])
@@ -196,6 +197,7 @@ class FusionCouplerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, feats, tok, *P):
         K = backend()
+        ctx.set_materialize_grads(False)
         feats, tok = feats.contiguous(), tok.contiguous()
         b, ts, e = feats.shape
         k = min(cfg.k, ts)

@@ -101,6 +101,7 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, spec, in_scale, in_shift, slope, residual, out_scale, want_stats, carry):
         K = backend()
+        ctx.set_materialize_grads(False)     # (autograd would zero-FILL a gradient for each of the (scale, shift) outputs: 2 launches per conv)
         n = x.shape[0]
         spec.uses += 1
         stats = K.new_stats(n, spec.cout, x.device) if want_stats else None
@@ -123,6 +124,8 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _a, _b, dcarry):
         K = backend()
+        if dy is None:                       # y itself unused downstream: only the carried alias has a gradient
+            return dcarry, None, None, None, None, None, None, None, None, None, None
         x, w, in_scale, in_shift, out_scale = ctx.saved_tensors
         spec = ctx.spec
         if out_scale is not None:
@@ -497,6 +500,71 @@ class _ChannelSoftmaxFn(torch.autograd.Function):
 
 def channel_softmax(logit):
     return _ChannelSoftmaxFn.apply(logit)
+
+
+class LazyProb:
+    """A sub-region probability map that has not been written yet: softmax(trilinear_up(logit)) of a supervision head
+    (SuperviseLabel.py:58-81) in TRAINING mode.  The package's own losses (utils.tools.get_separate_loss /
+    get_edge_separate_loss) recognise it and compute Dice / CE straight from the low-resolution logits (cwf_head_loss_*): the
+    [N,2,D,H,W] map, its gradient and four more full-resolution passes never exist.  Anything else that touches it -- indexing,
+    a torch function, a tensor method -- materialises the real map through the ordinary upsample_softmax Function (same values,
+    autograd intact), so code written against the reference's tensors keeps working."""
+
+    def __init__(self, logit, c, scale):
+        self.logit, self.c, self.scale = logit, c, scale
+        self._t = None
+
+    def materialize(self):
+        if self._t is None:
+            self._t = upsample_softmax(self.logit, self.c, self.scale).permute(0, 4, 1, 2, 3)      # logical [N,C,D,H,W]
+        return self._t
+
+    @property
+    def shape(self):
+        n, d, h, w, _ = self.logit.shape
+        s = self.scale
+        return torch.Size((n, self.c, d * s, h * s, w * s))
+
+    def __getattr__(self, name):                 # tensor attributes / methods (only reached for names not defined above)
+        return getattr(self.materialize(), name)
+
+    def __getitem__(self, idx):
+        return self.materialize()[idx]
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        real = lambda a: a.materialize() if isinstance(a, LazyProb) else a
+        return func(*[real(a) for a in args], **{k: real(v) for k, v in (kwargs or {}).items()})
+
+
+class _HeadGroupLossFn(torch.autograd.Function):
+    """sum over the (up to three) sub-region maps of one supervision call of dice_loss + softmax_weighted_loss, from the
+    low-resolution logits (tools.py:112-231 on top of SuperviseLabel.py:62-64)."""
+
+    @staticmethod
+    def forward(ctx, label, posmasks, scale, *logits):
+        K = backend()
+        logits = [t.contiguous() for t in logits]
+        total, _, coef = K.head_loss(logits, label, posmasks, scale)
+        ctx.posmasks, ctx.scale = posmasks, scale
+        ctx.save_for_backward(label, coef, *logits)
+        return total.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        label, coef = ctx.saved_tensors[:2]
+        logits = ctx.saved_tensors[2:]
+        gs = g.reshape(1).to(torch.float32).contiguous()
+        dls = backend().head_loss_bwd(list(logits), label, ctx.posmasks, ctx.scale, coef, gs)
+        return (None, None, None) + tuple(dls)
+
+
+def head_group_loss(lazies, label, posmasks):
+    """lazies: LazyProb maps of one supervision call (same shape / scale)."""
+    label = label.contiguous()
+    if label.dtype != torch.int64:
+        label = label.long()
+    return _HeadGroupLossFn.apply(label, tuple(int(m) for m in posmasks), lazies[0].scale, *[z.logit for z in lazies])
 
 
 class _DiceCeFn(torch.autograd.Function):

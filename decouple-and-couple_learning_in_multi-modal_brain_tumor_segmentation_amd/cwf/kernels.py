@@ -667,6 +667,37 @@ class HipBackend:
                    n, d * h * w, c, self._stream())
         return dprob
 
+    def head_loss(self, logits, label, posmasks, scale):
+        """Fused head -> loss forward: logits = up to 3 low-res [N,d,h,w,ldc] tensors (2 channels used), label int64 [N,D,H,W].
+        -> (total [1], loss [nm], coef [nm,N,2,4])"""
+        nm = len(logits)
+        n, d, h, w, ldc = logits[0].shape
+        assert all(t.shape == logits[0].shape and t.is_contiguous() for t in logits) and label.is_contiguous()
+        dev = logits[0].device
+        sums = self._zeros_f64((nm, n, 2, 4), dev)
+        ptrs = (ctypes.c_void_p * nm)(*[t.data_ptr() for t in logits])
+        masks = (ctypes.c_uint32 * nm)(*[int(m) for m in posmasks])
+        self._call("cwf_head_loss_sums", ctypes.addressof(ptrs), nm, ldc, ctypes.addressof(masks), label.data_ptr(), sums.data_ptr(), n, d, h, w, scale, self._stream())
+        loss = torch.empty(nm, dtype=_f32, device=dev)
+        total = torch.empty(1, dtype=_f32, device=dev)
+        coef = torch.empty((nm, n, 2, 4), dtype=_f32, device=dev)
+        self._call("cwf_dice_ce_finalize_multi", sums.data_ptr(), loss.data_ptr(), coef.data_ptr(), total.data_ptr(), nm, n,
+                   d * h * w * scale ** 3, 2, self._stream())
+        return total, loss, coef
+
+    def head_loss_bwd(self, logits, label, posmasks, scale, coef, gscale):
+        nm = len(logits)
+        n, d, h, w, ldc = logits[0].shape
+        dev = logits[0].device
+        dls = [torch.empty_like(t) for t in logits]
+        ws = self.workspace("head_loss_bwd", nm * n * d * scale * h * w * 2, dev)
+        ptrs = (ctypes.c_void_p * nm)(*[t.data_ptr() for t in logits])
+        dptrs = (ctypes.c_void_p * nm)(*[t.data_ptr() for t in dls])
+        masks = (ctypes.c_uint32 * nm)(*[int(m) for m in posmasks])
+        self._call("cwf_head_loss_bwd", ctypes.addressof(ptrs), nm, ldc, ctypes.addressof(masks), label.data_ptr(), coef.data_ptr(), gscale.data_ptr(),
+                   ctypes.addressof(dptrs), ldc, ws.data_ptr(), n, d, h, w, scale, self._stream())
+        return dls
+
     # ------------------------------------------------------------------ K11 / misc
     def adam(self, table, ntensors, max_n, lr, beta1, beta2, eps, wd, step, amsgrad, hyper_dev=None):
         self._call("cwf_adam_amsgrad", table.data_ptr(), ntensors, max_n, lr, beta1, beta2, eps, wd, step, int(amsgrad),

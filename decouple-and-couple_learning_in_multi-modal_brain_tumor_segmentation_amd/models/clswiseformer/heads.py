@@ -8,10 +8,17 @@ from cwf import functional as CF
 from .layers import HipConv
 
 
+import torch
+
+
 class _Heads(nn.Module):
+    lazy_training_maps = True                     # training mode returns CF.LazyProb (head -> loss fusion); set False for real tensors
+
     def _head(self, first, second, x):
         h, _ = first(x)
         logit, _ = second(h)                      # [N,d,h,w,4], channels 2..3 zero
+        if self.training and self.lazy_training_maps and torch.is_grad_enabled():
+            return CF.LazyProb(logit, 2, self.sample_scale)      # the losses read the low-res logits; nothing is written at 128^3
         prob = CF.upsample_softmax(logit, 2, self.sample_scale)
         return prob.permute(0, 4, 1, 2, 3)        # logical [N,2,D,H,W], channels-last memory
 

@@ -22,14 +22,24 @@ def dice_ce(output, target, num_cls=4, posmask=0):
     return CF.dice_ce_loss(output, target, posmask)
 
 
+def _separate(output, target, masks):
+    maps = [output[r] for r in ("01", "02", "04")]
+    if all(isinstance(m, CF.LazyProb) for m in maps) and len({(m.scale, tuple(m.logit.shape)) for m in maps}) == 1:
+        # training-mode outputs of this package's heads: Dice / CE straight from the low-resolution logits, one label read for
+        # the three sub-regions, no full-resolution map (cwf_head_loss_*)
+        return CF.head_group_loss(maps, target, [masks[r] for r in ("01", "02", "04")])
+    return sum(dice_ce(torch.as_tensor(output[r]) if not isinstance(output[r], CF.LazyProb) else output[r].materialize(), target, 2, masks[r])
+               for r in ("01", "02", "04"))
+
+
 def get_separate_loss(output, target):
     """tools.get_separate_loss (tools.py:112-162): three binary problems {target == k}, k = 1, 2, 3."""
-    return sum(dice_ce(output[r], target, 2, REGION_MASKS[r]) for r in ("01", "02", "04"))
+    return _separate(output, target, REGION_MASKS)
 
 
 def get_edge_separate_loss(output, target):
     """tools.get_edge_separate_loss (tools.py:165-231) on edge codes in {0,1,2,4,5,6,7,8}."""
-    return sum(dice_ce(output[r], target, 2, EDGE_MASKS[r]) for r in ("01", "02", "04"))
+    return _separate(output, target, EDGE_MASKS)
 
 
 def all_reduce_tensor(tensor, op=dist.ReduceOp.SUM, world_size=1):

@@ -312,6 +312,18 @@ int cwf_channel_softmax_bwd(const float* dprob, const float* prob, float* dlogit
 int cwf_dice_ce_sums(const float* prob, const int64_t* label, uint32_t posmask, double* sums,
                      int N, int64_t V, int C, void* stream);
 int cwf_dice_ce_finalize(const double* sums, float* loss, float* coef, int N, int64_t V, int C, void* stream);
+/* nmaps problems back to back (sums [nmaps][N][C][4], loss [nmaps], coef [nmaps][N][C][4]); total[0] = sum of the losses (nullable) */
+int cwf_dice_ce_finalize_multi(const double* sums, float* loss, float* coef, float* total, int nmaps, int N, int64_t V, int C, void* stream);
+/* Fused head -> loss (training mode): the sums above for up to three sub-region maps of one supervision call straight from their
+ * LOW-resolution 2-channel logits [N][D][H][W][l_ldc] -- trilinear x scale (align_corners=False) + softmax evaluated in registers,
+ * one shared read of the label volume, nothing written at full resolution (SuperviseLabel.py:58-81 -> tools.py:112-231).
+ * h_logits / h_posmasks / h_dlogits are HOST arrays of nmaps entries.  Backward: dlogits[m] [N][D][H][W][dl_ldc] WRITTEN (channels
+ * >= 2 zeroed) from (label, coef, gscale); workspace: nmaps * N * D*scale * H * W * 2 floats.                                      */
+int cwf_head_loss_sums(const float* const* h_logits, int nmaps, int l_ldc, const uint32_t* h_posmasks, const int64_t* label,
+                       double* sums, int N, int D, int H, int W, int scale, void* stream);
+int cwf_head_loss_bwd(const float* const* h_logits, int nmaps, int l_ldc, const uint32_t* h_posmasks, const int64_t* label,
+                      const float* coef, const float* gscale, float* const* h_dlogits, int dl_ldc, float* workspace,
+                      int N, int D, int H, int W, int scale, void* stream);
 int cwf_dice_ce_bwd(const float* prob, const int64_t* label, uint32_t posmask, const float* coef, const float* gscale,
                     float* dprob, int N, int64_t V, int C, void* stream);
 

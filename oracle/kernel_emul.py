@@ -527,6 +527,24 @@ class EmulBackend:
         g = k[..., 1] + t * (k[..., 0] + inside * k[..., 2] / prob)
         return gscale[0] * g
 
+    def head_loss(self, logits, label, posmasks, scale):
+        """cwf_head_loss_sums + cwf_dice_ce_finalize_multi: per map, the unfused chain upsample_softmax -> dice_ce."""
+        outs = [self.dice_ce(self.upsample_softmax(lg, 2, scale), label, int(pm)) for lg, pm in zip(logits, posmasks)]
+        loss = torch.cat([o[0] for o in outs])
+        total = torch.zeros(1)
+        for v in loss:
+            total = total + v
+        return total, loss, torch.stack([o[1] for o in outs])
+
+    def head_loss_bwd(self, logits, label, posmasks, scale, coef, gscale):
+        dls = []
+        for m, (lg, pm) in enumerate(zip(logits, posmasks)):
+            prob = self.upsample_softmax(lg, 2, scale)
+            dprob = self.dice_ce_bwd(prob, label, int(pm), coef[m], gscale)
+            n, d, h, w, ldc = lg.shape
+            dls.append(self.upsample_softmax_bwd(dprob, prob, (n, d, h, w), 2, scale, ldc))
+        return dls
+
     # ------------------------------------------------------------------ K11 / misc
     def adam(self, table, ntensors, max_n, lr, beta1, beta2, eps, wd, step, amsgrad, hyper_dev=None):
         """Pointer-table form of torch.optim.Adam(amsgrad, weight_decay) -- optim.hip / train_no_amp.py:136,239.  Host

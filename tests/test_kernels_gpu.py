@@ -305,6 +305,52 @@ def test_upsample_softmax_heads(hip, scale, lo):
     close(hip.channel_softmax_bwd(d4.to(DEV), p4), E.channel_softmax_bwd(d4, p4.cpu()), rtol=1e-5)
 
 
+@pytest.mark.parametrize("scale,lo,codes", [(8, (4, 6, 4), (0, 1, 2, 3)), (4, (8, 8, 12), (0, 1, 2, 4, 5, 6, 7, 8)), (8, (16, 16, 16), (0, 1, 2, 3))])
+def test_head_loss_fused_vs_unfused_chain(hip, scale, lo, codes):
+    """Head -> loss fusion: Dice/CE sums, losses and the logit gradients of three sub-region maps computed straight from the
+    low-resolution logits (cwf_head_loss_*) against (a) the kernel oracle and (b) the UNFUSED HIP chain upsample_softmax ->
+    dice_ce -> backward, whose probabilities the fused kernels reproduce with identical arithmetic."""
+    from cwf import functional as CF
+    from utils import tools
+    n = 2
+    hi = tuple(v * scale for v in lo)
+    logits = []
+    for m in range(3):
+        lg = torch.zeros(n, *lo, 4)
+        lg[..., :2] = rnd(n, *lo, 2, seed=m + 1) * 4          # up to |8| logit difference: probabilities on both sides of the 0.005 clamp
+        logits.append(lg)
+    g = torch.Generator().manual_seed(5)
+    label = torch.tensor(codes)[torch.randint(0, len(codes), (n,) + hi, generator=g)]
+    masks = [tools.REGION_MASKS, tools.EDGE_MASKS][len(codes) > 4]
+    pm = [masks[r] for r in ("01", "02", "04")]
+    ld = [t.to(DEV) for t in logits]
+    total, loss, coef = hip.head_loss(ld, label.to(DEV), pm, scale)
+    t_e, l_e, c_e = E.head_loss(logits, label, pm, scale)
+    close(loss, l_e, rtol=2e-6, what="fused losses"); close(total, t_e, rtol=2e-6); close(coef, c_e, rtol=1e-5, what="coef")
+    gs = torch.tensor([0.7])
+    dls = hip.head_loss_bwd(ld, label.to(DEV), pm, scale, coef, gs.to(DEV))
+    dls_e = E.head_loss_bwd(logits, label, pm, scale, c_e, gs)
+    for a, b in zip(dls, dls_e):
+        close(a, b, rtol=5e-5, what="fused dlogit")
+        assert float(a[..., 2:].abs().max()) == 0.0                      # pad channels written as zeros
+    # (b) unfused HIP chain, through autograd, on the same logits
+    leaves = [t.clone().requires_grad_(True) for t in ld]
+    unf = sum(tools.dice_ce(CF.upsample_softmax(t, 2, scale).permute(0, 4, 1, 2, 3), label.to(DEV), 2, m) for t, m in zip(leaves, pm))
+    (unf * 0.7).backward()
+    assert abs(float(unf) - float(total)) <= 2e-6 * abs(float(unf))
+    for a, t in zip(dls, leaves):
+        close(a, t.grad, rtol=2e-5, what="fused vs unfused dlogit")
+    # the lazy map: the losses take the fused route, anything else sees the real tensor
+    lz = {r: CF.LazyProb(t.clone().requires_grad_(True), 2, scale) for r, t in zip(("01", "02", "04"), ld)}
+    fused = (tools.get_separate_loss if len(codes) == 4 else tools.get_edge_separate_loss)(lz, label.to(DEV))
+    assert abs(float(fused) - float(total)) <= 1e-6 * abs(float(total)) and all(z._t is None for z in lz.values())
+    (fused * 0.7).backward()
+    close(lz["02"].logit.grad, dls[1], rtol=1e-6)
+    assert lz["01"].shape == (n, 2) + hi
+    real = CF.upsample_softmax(ld[0], 2, scale).permute(0, 4, 1, 2, 3)
+    assert torch.equal(lz["01"].detach(), real) and torch.equal(torch.argmax(lz["01"], dim=1), real.argmax(1)) and torch.equal(lz["01"][:, 1], real[:, 1])
+
+
 def test_losses_against_reference_fixture(hip):
     """The HIP Dice/CE path on the reference's own golden losses (tests/golden/losses.npz, produced by the imported
     reference utils.tools / models.criterions)."""
