@@ -188,6 +188,10 @@ def main():
     ap.add_argument("--no-wgrad-async", action="store_true", help="keep the weight gradients on the main stream (A/B)")
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
                     help="MFMA operand form of the conv family (storage and accumulation are fp32 in every mode)")
+    ap.add_argument("--wgrad-precision", default="bf16", choices=["bf16x3", "bf16", "fp32"],
+                    help="operand form of the weight-gradient kernels (default: single bf16 products, fp32 accumulate -- gradient norms stay "
+                         "within the fp32 reference's own noise of the float64 gradients, tests/test_model_gpu.py)")
+    ap.add_argument("--dgrad-precision", default="bf16", choices=["bf16x3", "bf16", "fp32"], help="operand form of the data-gradient kernels")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -210,7 +214,9 @@ def main():
     from models.clswiseformer.cls_wise_former import get_cls_wise_former
     from cwf.trainer import Trainer
     from cwf import kernels
-    kernels.set_precision(args.precision)
+    if args.precision == "fp32":
+        args.wgrad_precision = args.dgrad_precision = "fp32"
+    kernels.set_precision(args.precision, args.wgrad_precision, args.dgrad_precision)
     from utils import synthetic as syn
 
     torch.manual_seed(1000 + rank)                       # train_no_amp.py:85 seed, per-rank streams
@@ -253,13 +259,16 @@ def main():
             "metric": "training volumes/sec (4x128^3)", "value": round(value, 3), "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA operands hi.hi+hi.lo+lo.hi, f32 accumulate, f32 storage)",
-                      "bf16": "bf16 (MFMA operands; f32 accumulate, f32 storage)"}[args.precision], "data": "synthetic",
+            "dtype": {"fp32": "f32", "bf16x3": "bf16x3 forward (split-bf16 MFMA operands hi.hi+hi.lo+lo.hi: logits within 1e-3 of the fp32 reference)",
+                      "bf16": "bf16 forward"}[args.precision] +
+                     ("" if args.precision == "fp32" else " / %s data-gradient / %s weight-gradient MFMA operands; f32 accumulate, f32 storage, f32 master weights"
+                      % (args.dgrad_precision, args.wgrad_precision)), "data": "synthetic",
             "config": {"workload": "%s: %dxMI355X, batch %d per GPU, 4-modality %d^3 synthetic BraTS patches; "
                                    "fwd + softmax_dice + 4 sub-region/edge losses + bwd + Adam(amsgrad)%s; random-init weights, dropout on"
                                    % ("configs[1]" if world == 1 else ("configs[2]" if world == 8 else "configs[1] per GPU, data-parallel"),
                                       world, args.batch, args.size, "" if world == 1 else " + gradient all-reduce (RCCL)"),
-                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "precision": args.precision, "graph": bool(args.graph)},
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "precision": args.precision, "dgrad_precision": args.dgrad_precision,
+                       "wgrad_precision": args.wgrad_precision, "graph": bool(args.graph)},
             "final_loss": round(final_loss, 5), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 2),
             "end_to_end": {"tflops": round(value * FLOP_PER_TRAIN_VOLUME * (args.size / 128.0) ** 3 / 1e12, 2),
                            "frac_mfma_peak_for_mode": round(value * FLOP_PER_TRAIN_VOLUME * (args.size / 128.0) ** 3 / 1e12 / world / MFMA_PEAK_TFLOPS[args.precision], 4)},

@@ -45,13 +45,21 @@ def _p(t):
 #   "bf16x3" split-bf16: hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16, fp32 accumulate (~2^-16 per product)
 #   "bf16"   single bf16 product (2^-9 per product)
 _PRECISION = "fp32"
+_WGRAD_PRECISION = None      # None = follow _PRECISION; "bf16" = single-bf16 products for the weight gradients only (see set_precision)
+_DGRAD_PRECISION = None      # the same for the data-gradient convolutions
 
 
-def set_precision(mode: str):
-    global _PRECISION
-    if mode not in ("fp32", "bf16x3", "bf16"):
+def set_precision(mode: str, wgrad: str = None, dgrad: str = None):
+    """`wgrad` / `dgrad` optionally select the operand form of the weight-gradient / data-gradient kernels alone ("bf16": one
+    bf16 product, fp32 accumulate -- the usual mixed-precision choice for gradients), leaving the forward in `mode`."""
+    global _PRECISION, _WGRAD_PRECISION, _DGRAD_PRECISION
+    ok = ("fp32", "bf16x3", "bf16")
+    if mode not in ok or wgrad not in (None,) + ok or dgrad not in (None,) + ok:
         raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16'")
-    _PRECISION = mode
+    for o in (wgrad, dgrad):
+        if o is not None and (mode == "fp32") != (o == "fp32"):
+            raise ValueError("the fp32 and the bf16 kernel families use different weight packings; choose all from one family")
+    _PRECISION, _WGRAD_PRECISION, _DGRAD_PRECISION = mode, wgrad, dgrad
 
 
 def precision() -> str:
@@ -171,7 +179,7 @@ class HipBackend:
         r_ldc = 0
         if residual is not None:
             residual, r_ldc = cl(residual)
-        mode = prec or _PRECISION
+        mode = prec or ((_DGRAD_PRECISION or _PRECISION) if (fwd_op is not None) else _PRECISION)
         if mode == "fp32":
             self._call("cwf_conv_mfma", op, x.data_ptr(), x_ldc, wpk.data_ptr(), _p(bias), y.data_ptr(), y_ldc,
                        _p(in_scale), _p(in_shift), float(slope), _p(residual), r_ldc, _p(out_scale), _p(stats),
@@ -246,7 +254,7 @@ class HipBackend:
         if nsplit <= 0 or slab <= 0 or slab != inv_map.numel():
             raise _lib.CwfError("cwf_wgrad plan failed (%d, %d, %d)" % (nsplit, slab, inv_map.numel()))
         part = self.workspace("wgrad", nsplit * slab, x.device)
-        mode = prec or _PRECISION
+        mode = prec or _WGRAD_PRECISION or _PRECISION
         if mode == "fp32":
             self._call("cwf_wgrad_mfma", op, x.data_ptr(), x_ldc, _p(in_scale), _p(in_shift), float(slope),
                        dy.data_ptr(), dy_ldc, part.data_ptr(), n, di, hi, wi, cin, do, ho, wo, cout, self._stream())
