@@ -21,12 +21,12 @@ extern "C" int cwf_gather_batched(const struct cwf_gather_desc* table, int nlaye
 }
 
 __global__ void adam_kernel(const cwf_adam_desc* __restrict__ table, const float* __restrict__ hyper, float step_size, float omb1, float beta2,
-                            float omb2, float eps, float wd, float bc2_sqrt, int amsgrad) {
+                            float omb2, float eps, float wd, float bc2_sqrt, int amsgrad, float gscale) {
   const cwf_adam_desc d = table[blockIdx.y];
   if (hyper) { step_size = hyper[0]; bc2_sqrt = hyper[1]; }        // device-resident: survives hipGraph replay
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * blockDim.x) {
     const float p = d.p[i];
-    const float g = d.g[i] + wd * p;                                 // grad.add(param, alpha=weight_decay)
+    const float g = fmaf(wd, p, d.g[i] * gscale);                      // (gscale = 1/world: the gradient AVERAGE over ranks) grad.add(param, alpha=weight_decay)
     const float m = d.m[i] + omb1 * (g - d.m[i]);                    // exp_avg.lerp_(grad, 1 - beta1)
     const float v = beta2 * d.v[i] + omb2 * g * g;                   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
     d.m[i] = m; d.v[i] = v;
@@ -40,12 +40,18 @@ __global__ void adam_kernel(const cwf_adam_desc* __restrict__ table, const float
 extern "C" int cwf_adam_amsgrad(const struct cwf_adam_desc* table, int ntensors, int64_t max_n,
                                 double lr, double beta1, double beta2, double eps, double weight_decay, int step, int amsgrad,
                                 const float* hyper_dev, void* stream) {
+  return cwf_adam_amsgrad_scaled(table, ntensors, max_n, lr, beta1, beta2, eps, weight_decay, step, amsgrad, hyper_dev, 1.0f, stream);
+}
+
+extern "C" int cwf_adam_amsgrad_scaled(const struct cwf_adam_desc* table, int ntensors, int64_t max_n,
+                                       double lr, double beta1, double beta2, double eps, double weight_decay, int step, int amsgrad,
+                                       const float* hyper_dev, float grad_scale, void* stream) {
   if (!table || ntensors <= 0 || max_n <= 0 || (step <= 0 && !hyper_dev)) return CWF_E_BADARG;
   const double bc1 = 1.0 - pow(beta1, (double)(step > 0 ? step : 1));
   const double bc2 = 1.0 - pow(beta2, (double)(step > 0 ? step : 1));
   int64_t gx = cdiv64(max_n, 256); if (gx > 64) gx = 64;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gx, ntensors), dim3(256), 0, cwf_stream(stream), table, hyper_dev, (float)(lr / bc1),
-                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)sqrt(bc2), amsgrad);
+                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)sqrt(bc2), amsgrad, grad_scale);
   CWF_LAUNCH_CHECK();
   return 0;
 }

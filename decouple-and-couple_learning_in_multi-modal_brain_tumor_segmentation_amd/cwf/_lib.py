@@ -57,6 +57,8 @@ SIGNATURES = {
     "cwf_dice_ce_finalize": [P, P, P, I, L, I, P],
     "cwf_dice_ce_bwd": [P, P, U, P, P, P, I, L, I, P],
     "cwf_adam_amsgrad": [P, I, L, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P, P],
+    "cwf_adam_amsgrad_scaled": [P, I, L, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, I, P, F, P],
+    "cwf_wgrad_reduce_batched": [P, I, P],
     "cwf_dropout_mask": [P, L, F, F, C.c_uint64, C.c_uint64, P],
     "cwf_mul": [P, P, P, L, P],
     "cwf_add": [P, P, P, L, P],

@@ -54,6 +54,20 @@ def transformer_params(model):
             ff.norm.weight, ff.norm.bias, ff.fn.net[0].weight, ff.fn.net[0].bias, ff.fn.net[3].weight, ff.fn.net[3].bias)
 
 
+def _grad_buffers(P):
+    """Destination of the weight-set gradients: slices of the Trainer's flat gradient buffer when a sink is active (the
+    Functions then return None for them: autograd never sees these gradients), fresh tensors otherwise."""
+    from .optim import active_sink
+    sink = active_sink()
+    if sink is not None:
+        views = [sink.view(p) for p in P]
+        if all(v is not None for v in views):
+            for p in P:
+                sink.mark(p)
+            return views, True
+    return [torch.empty_like(p) for p in P], False
+
+
 def _site(K, cfg_p, n):
     return K.rng_site(n) if cfg_p > 0.0 else 0
 
@@ -162,6 +176,7 @@ class RegionCouplerFn(torch.autograd.Function):
         gated_s, scat_s = K.scatter_inv(S, inv_s, R[:, 1, 1:], R[:, 1, 0:1], want_gated=True, want_scat=True)
         sem_tok = R[:, 1, 0:1]
         ctx.cfg, ctx.sv, ctx.offs, ctx.k = cfg, (sv1, sv2, sv3), offs, k
+        ctx.toks = (e_tok, s_tok)
         ctx.save_for_backward(E, S, R, idx_e, inv_e, inv_es, idx_s, inv_s, inv_se, *P)
         idx = (idx_e, idx_se, idx_s, idx_es)
         ctx.mark_non_differentiable(*idx)
@@ -176,7 +191,7 @@ class RegionCouplerFn(torch.autograd.Function):
         b, _, t, e = R.shape
         c = lambda g: None if g is None else g.contiguous()
         dgated_e, dgated_s, dscat_s, dsem_tok = c(dgated_e), c(dgated_s), c(dscat_s), c(dsem_tok)
-        G = [torch.empty_like(p) for p in P]
+        G, sunk = _grad_buffers(P)
         dR = torch.empty_like(R)
         K.scatter_bwd(dgated_e, None, E, inv_e, idx_e, R[:, 0, 1:], R[:, 0, 0:1], None, dR[:, 0, 1:], dR[:, 0, 0:1])
         K.scatter_bwd(dgated_s, dscat_s, S, inv_s, idx_s, R[:, 1, 1:], R[:, 1, 0:1], dsem_tok, dR[:, 1, 1:], dR[:, 1, 0:1])
@@ -187,8 +202,12 @@ class RegionCouplerFn(torch.autograd.Function):
         dX1, dX2 = dx1.view(b, 2, t, e), dx2.view(b, 2, t, e)
         dE = K.token_grad(dgated_e, None, R[:, 0, 0:1], inv_e, inv_es, dX1[:, 0], dX2[:, 1], k, cfg.p_select, offs[0], offs[3])
         dS = K.token_grad(dgated_s, dscat_s, R[:, 1, 0:1], inv_s, inv_se, dX1[:, 1], dX2[:, 0], k, cfg.p_select, offs[1], offs[2])
-        d_etok, d_stok = K.head_grad(dX1[:, 0, 0], dX2[:, 1, 0], dX1[:, 1, 0], dX2[:, 0, 0])
-        return (None, dE, dS, d_etok, d_stok) + tuple(G)
+        e_tok, s_tok = ctx.toks
+        (tk, tk_sunk) = _grad_buffers((e_tok, s_tok))
+        d_etok, d_stok = K.head_grad(dX1[:, 0, 0], dX2[:, 1, 0], dX1[:, 1, 0], dX2[:, 0, 0], out1=tk[0], out2=tk[1])
+        if tk_sunk:
+            d_etok = d_stok = None
+        return (None, dE, dS, d_etok, d_stok) + (tuple(G) if not sunk else (None,) * len(G))
 
 
 class FusionCouplerFn(torch.autograd.Function):
@@ -224,14 +243,14 @@ class FusionCouplerFn(torch.autograd.Function):
         P = ctx.saved_tensors[4:]
         b, t, e = R.shape
         dfused = dfused.contiguous()
-        G = [torch.empty_like(p) for p in P]
+        G, sunk = _grad_buffers(P)
         dR = torch.empty_like(R)
         K.scatter_bwd(dfused, None, feats, inv, idx, R[:, 1:], R[:, 0:1], None, dR[:, 1:], dR[:, 0:1])
         dy1 = _ffn_bwd(K, P, G, sv2, dR.view(b * t, e))
         dx, _ = _ca_bwd(K, P, G, cfg, sv1, dy1, first=True, dual=False)
         dX = dx.view(b, t, e)
         dfeats = K.token_grad(dfused, None, R[:, 0:1], inv, None, dX, None, k, cfg.p_select, off, 0)
-        return (None, dfeats, dX[:, 0:1]) + tuple(G)
+        return (None, dfeats, dX[:, 0:1]) + (tuple(G) if not sunk else (None,) * len(G))
 
 
 class _Add3Fn(torch.autograd.Function):

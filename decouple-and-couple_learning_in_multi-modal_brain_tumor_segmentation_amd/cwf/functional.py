@@ -17,6 +17,11 @@ from . import packing as pk
 from .kernels import backend, precision
 
 
+def active_sink():
+    from .optim import active_sink as f
+    return f()
+
+
 # ======================================================================================================
 # per-layer conv description + once-per-step weight packing
 # ======================================================================================================
@@ -108,6 +113,7 @@ class _ConvFn(torch.autograd.Function):
         y = K.conv(spec.op, x, spec.packed(False), b, spec.cout, in_scale, in_shift, slope, residual, out_scale, stats,
                    w_ref=w, out_channels_alloc=spec.cout_alloc)
         ctx.spec, ctx.slope = spec, slope
+        ctx.bias_ref = b
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, w, in_scale, in_shift, out_scale)
         # carry: x is handed on as a second output (an alias).  Whatever consumes that alias (a residual connection, a skip
@@ -132,7 +138,20 @@ class _ConvFn(torch.autograd.Function):
             dy = K.channel_scale(dy, out_scale)
         dres = dy if ctx.has_res else None
         dw = db = dx = None
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+        sink = active_sink()
+        sw = sink.view(w) if (sink is not None and spec.uses <= 1 and ctx.needs_input_grad[1]) else None
+        sb = sink.view(ctx.bias_ref) if (sw is not None and ctx.bias_ref is not None) else None
+        if sw is not None and (ctx.bias_ref is None or sb is not None):
+            # gradient-sink path (Trainer): slabs now, ONE batched reduce per backward phase writes dW / db into the flat buffer
+            dyv = dy[..., :spec.cout] if dy.shape[-1] != spec.cout else dy
+            K.wgrad_to(spec, spec.op, x, in_scale, in_shift, ctx.slope, dyv, spec.cout, spec.inv_map, sw, sb if spec.has_bias_map else None,
+                       allow_async=not ctx.has_res)
+            sink.mark(w)
+            if sb is not None:
+                if not spec.has_bias_map:   # ConvTranspose: the bias gradient spans the 8 parity classes
+                    sb.copy_(K.in_stats(dy)[:, :, 0].sum(0))
+                sink.mark(ctx.bias_ref)
+        elif ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dyv = dy[..., :spec.cout] if dy.shape[-1] != spec.cout else dy
             # side-stream weight gradients only where nothing on the main stream can touch their operands or results early:
             #  * a weight applied twice in the forward, or a .grad that already exists, makes AccumulateGrad add IN PLACE;

@@ -84,6 +84,9 @@ class HipBackend:
         self._rng_seed = {}
         self._site = 0                         # per-step dropout-site offset (reset by begin_step, static across steps)
         self._wg_stream = {}                   # device -> side stream for weight gradients (opt-in, see wgrad_stream)
+        self._wg_part = {}                     # layer key -> persistent split-K slab buffer (wgrad_to)
+        self._wg_pending = []                  # descriptor rows awaiting the batched reduce (wgrad_flush)
+        self._wg_tables = {}
         self.wgrad_async = False
         self._rng_lock = threading.Lock()      # the autograd engine may call in from its own thread
 
@@ -242,6 +245,73 @@ class HipBackend:
                     t.record_stream(side)
             return out
         return self._wgrad_impl(op, x, in_scale, in_shift, slope, dy, cout, inv_map, has_bias_map, w_numel, w_ref_shape, prec)
+
+    # Gradient-sink form (cwf.optim.GradSink, used by the Trainer): the layer's split-K slabs go to a buffer of its own and the
+    # reduction of ALL layers of a backward phase is one launch (wgrad_flush) that writes dW / db straight into the flat gradient
+    # buffer -- no per-layer reduce launch, no per-layer gradient tensors, no concatenation before the optimizer.
+    def wgrad_to(self, key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec=None, allow_async=False):
+        if self.wgrad_async and allow_async:
+            side = self.wgrad_stream(x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side):
+                self._wgrad_to_impl(key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec)
+            for t in (x, dy, in_scale, in_shift):
+                if t is not None:
+                    t.record_stream(side)
+        else:
+            self._wgrad_to_impl(key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec)
+            self._wg_sync_needed = self.wgrad_async          # a main-stream producer: the side-stream reduce must wait for it
+
+    def _wgrad_to_impl(self, key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec):
+        x, x_ldc = cl(x)
+        dy, dy_ldc = cl(dy)
+        n, di, hi, wi, cin = x.shape
+        _, do, ho, wo, _ = dy.shape
+        nsplit = self.lib.cwf_wgrad_nsplit(op, n, do, ho, wo, cin, cout)
+        slab = self.lib.cwf_wgrad_slab_floats(op, cin, cout)
+        if nsplit <= 0 or slab <= 0 or slab != inv_map.numel():
+            raise _lib.CwfError("cwf_wgrad plan failed (%d, %d, %d)" % (nsplit, slab, inv_map.numel()))
+        pk_ = (key, x.device, torch.cuda.is_current_stream_capturing())
+        part = self._wg_part.get(pk_)
+        if part is None or part.numel() < nsplit * slab:
+            part = torch.empty(int(nsplit * slab), dtype=_f32, device=x.device)
+            self._wg_part[pk_] = part
+        mode = prec or _WGRAD_PRECISION or _PRECISION
+        if mode == "fp32":
+            self._call("cwf_wgrad_mfma", op, x.data_ptr(), x_ldc, _p(in_scale), _p(in_shift), float(slope),
+                       dy.data_ptr(), dy_ldc, part.data_ptr(), n, di, hi, wi, cin, do, ho, wo, cout, self._stream())
+        else:
+            used = ctypes.c_int(0)
+            self._call("cwf_wgrad_mfma_bf16", op, 1 if mode == "bf16x3" else 0, x.data_ptr(), x_ldc, _p(in_scale), _p(in_shift),
+                       float(slope), dy.data_ptr(), dy_ldc, part.data_ptr(), n, di, hi, wi, cin, do, ho, wo, cout,
+                       ctypes.addressof(used), self._stream())
+            nsplit = used.value
+        self._wg_pending.append((part.data_ptr(), inv_map.data_ptr(), dw_dst.data_ptr(), _p(db_dst), int(slab), int(nsplit)))
+
+    def wgrad_flush(self, device=None):
+        """One batched reduce for every layer queued by wgrad_to since the last flush (on the weight-gradient side stream when
+        that is in use: it follows the queued kernels in stream order)."""
+        rows = self._wg_pending
+        if not rows:
+            return
+        self._wg_pending = []
+        device = device or torch.device("cuda", _current_device())
+        key = (device, tuple(rows))
+        table = self._wg_tables.get(key)
+        if table is None:                       # static across steps (persistent buffers, static shapes): built once
+            import struct
+            raw = b"".join(struct.pack("<QQQQqii", r[0], r[1], r[2], r[3], r[4], r[5], 0) for r in rows)
+            table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+            self._wg_tables[key] = table
+        if self.wgrad_async:
+            side = self.wgrad_stream(device)
+            if getattr(self, "_wg_sync_needed", False):
+                side.wait_stream(torch.cuda.current_stream(device))
+                self._wg_sync_needed = False
+            with torch.cuda.stream(side):
+                self._call("cwf_wgrad_reduce_batched", table.data_ptr(), len(rows), self._stream())
+        else:
+            self._call("cwf_wgrad_reduce_batched", table.data_ptr(), len(rows), self._stream())
 
     def _wgrad_impl(self, op, x, in_scale, in_shift, slope, dy, cout, inv_map, has_bias_map, w_numel, w_ref_shape=None, prec=None):
         """returns (dW flat [w_numel], db [cout] or None)"""
@@ -611,13 +681,13 @@ class HipBackend:
                    self.rng(dseq_p.device).data_ptr(), off_p, off_q, float(p), dfeats.data_ptr(), b, t, k, e, self._stream())
         return dfeats
 
-    def head_grad(self, a1, c1, a2, c2):
+    def head_grad(self, a1, c1, a2, c2, out1=None, out2=None):
         """out1 = sum_b (a1[b] + c1[b]), out2 = sum_b (a2[b] + c2[b]); inputs are [B,E] row views with a common batch stride"""
         b, e = a1.shape
         bs = a1.stride(0)
         assert c1.stride(0) == bs and a2.stride(0) == bs and c2.stride(0) == bs
-        o1 = torch.empty((1, 1, e), dtype=_f32, device=a1.device)
-        o2 = torch.empty((1, 1, e), dtype=_f32, device=a1.device)
+        o1 = out1 if out1 is not None else torch.empty((1, 1, e), dtype=_f32, device=a1.device)
+        o2 = out2 if out2 is not None else torch.empty((1, 1, e), dtype=_f32, device=a1.device)
         self._call("cwf_head_grad", a1.data_ptr(), c1.data_ptr(), a2.data_ptr(), c2.data_ptr(), bs, o1.data_ptr(), o2.data_ptr(), b, e, self._stream())
         return o1, o2
 
@@ -707,9 +777,9 @@ class HipBackend:
         return dls
 
     # ------------------------------------------------------------------ K11 / misc
-    def adam(self, table, ntensors, max_n, lr, beta1, beta2, eps, wd, step, amsgrad, hyper_dev=None):
-        self._call("cwf_adam_amsgrad", table.data_ptr(), ntensors, max_n, lr, beta1, beta2, eps, wd, step, int(amsgrad),
-                   _p(hyper_dev), self._stream())
+    def adam(self, table, ntensors, max_n, lr, beta1, beta2, eps, wd, step, amsgrad, hyper_dev=None, grad_scale=1.0):
+        self._call("cwf_adam_amsgrad_scaled", table.data_ptr(), ntensors, max_n, lr, beta1, beta2, eps, wd, step, int(amsgrad),
+                   _p(hyper_dev), float(grad_scale), self._stream())
 
     def dropout_mask(self, shape, p, device, p2=0.0):
         """Pre-scaled keep mask(s) in one launch from the device generator state (capturable: the state advances by a kernel)."""

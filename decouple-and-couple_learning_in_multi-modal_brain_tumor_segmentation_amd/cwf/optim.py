@@ -18,12 +18,86 @@ def poly_lr(init_lr, epoch, max_epoch, power=0.9):
     return round(init_lr * np.power(1 - epoch / max_epoch, power), 8)
 
 
+_ACTIVE_SINK = None
+
+
+def active_sink():
+    """The gradient sink backward kernels may write parameter gradients into (None outside Trainer-driven backward passes)."""
+    return _ACTIVE_SINK
+
+
+class GradSink:
+    """ONE flat fp32 buffer holding every parameter gradient, laid out in backward-completion order (`phases`: lists of
+    parameters; phase k is final once backward has passed the k-th cut point of the model).  While a sink is active the conv
+    weight-gradient reduction (cwf_wgrad_reduce_batched) and the coupler Functions write their parameter gradients straight
+    into their slices and return None to autograd: no per-parameter gradient tensors, no AccumulateGrad, no concatenation, and
+    the data-parallel all-reduce of a phase's contiguous slice can start while backward is still running (cwf.trainer)."""
+
+    def __init__(self, params, phases=None):
+        params = [p for p in params if p.requires_grad]
+        if phases is None:
+            phases = [params]
+        known = {id(p) for p in params}
+        order = [p for ph in phases for p in ph if id(p) in known]
+        if len(order) != len(params) or len({id(p) for p in order}) != len(params):
+            raise ValueError("phases must partition the parameter list")
+        dev = params[0].device
+        self.flat = torch.zeros(sum(p.numel() for p in order), dtype=torch.float32, device=dev)
+        self.params = order
+        self.views, self.chunks, off = {}, [], 0
+        for ph in phases:
+            start = off
+            for p in ph:
+                if id(p) in known:
+                    self.views[p.data_ptr()] = self.flat[off:off + p.numel()].view_as(p)
+                    off += p.numel()
+            self.chunks.append((start, off))
+        self.written = set()
+
+    def view(self, p):
+        """the slice of `p` (looked up by storage address: autograd may hand a Function a different Python object)"""
+        return self.views.get(p.data_ptr())
+
+    def mark(self, p):
+        self.written.add(p.data_ptr())
+
+    def begin(self):
+        self.written = set()
+
+    def __enter__(self):
+        global _ACTIVE_SINK
+        self._prev, _ACTIVE_SINK = _ACTIVE_SINK, self
+        return self
+
+    def __exit__(self, *a):
+        global _ACTIVE_SINK
+        _ACTIVE_SINK = self._prev
+
+    def finish(self):
+        """After backward: parameters whose gradient came through autograd (.grad) are copied in, parameters that received no
+        gradient at all are zeroed (their slices would otherwise keep the previous step's values)."""
+        srcs, dsts = [], []
+        for p in self.params:
+            if p.data_ptr() in self.written:
+                continue
+            v = self.views[p.data_ptr()]
+            if p.grad is not None:
+                srcs.append(p.grad); dsts.append(v)
+            else:
+                v.zero_()
+        if srcs:
+            torch._foreach_copy_(dsts, srcs)
+
+
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, phases=None):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
         if len(self.param_groups) != 1:
             raise ValueError("FusedAdam supports one parameter group (the reference uses one, train_no_amp.py:136)")
         self._plist = [p for p in self.param_groups[0]["params"] if p.requires_grad]
+        self._phases = phases
+        self.sink = None
+        self.grad_scale = 1.0
         self.flat_grad = None
         self._table = None
         self._max_n = 0
@@ -52,9 +126,11 @@ class FusedAdam(torch.optim.Optimizer):
         group = self.param_groups[0]
         dev = self._plist[0].device
         total = sum(p.numel() for p in self._plist)
-        if self.flat_grad is None or self.flat_grad.numel() != total or self.flat_grad.device != dev:
-            self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
-        rows, off = [], 0
+        if self.sink is None or self.sink.flat.numel() != total or self.sink.flat.device != dev or \
+                any(self.sink.view(p) is None for p in self._plist):
+            self.sink = GradSink(self._plist, self._phases)
+            self.flat_grad = self.sink.flat
+        rows = []
         for p in self._plist:
             st = self.state[p]
             if not st:
@@ -64,18 +140,18 @@ class FusedAdam(torch.optim.Optimizer):
                 if group["amsgrad"]:
                     st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             n = p.numel()
-            rows.append([p.data_ptr(), self.flat_grad.data_ptr() + 4 * off, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+            rows.append([p.data_ptr(), self.sink.view(p).data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                          st["max_exp_avg_sq"].data_ptr() if "max_exp_avg_sq" in st else 0, n])
-            off += n
         self._table = torch.tensor(rows, dtype=torch.int64).to(dev)
         self._table_key = self._key()
         self._max_n = max(r[5] for r in rows)
 
     # ------------------------------------------------------------------ the three phases of a step
     def gather_grads(self):
-        """p.grad -> flat_grad (one concatenation; capturable).  Parameters without a gradient contribute zeros."""
+        """p.grad -> flat gradient buffer for every parameter the backward kernels did not already write there (all of them
+        when no sink was active during backward): one multi-tensor copy; capturable."""
         self._ensure()
-        torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self._plist], out=self.flat_grad)
+        self.sink.finish()
         return self.flat_grad
 
     def advance_host(self):
@@ -92,7 +168,7 @@ class FusedAdam(torch.optim.Optimizer):
         group = self.param_groups[0]
         b1, b2 = group["betas"]
         backend().adam(self._table, len(self._plist), self._max_n, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
-                       self._steps, group["amsgrad"], hyper_dev=None)
+                       self._steps, group["amsgrad"], hyper_dev=None, grad_scale=self.grad_scale)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -100,6 +176,8 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self._ensure()
+        self.sink.begin()               # plain optimizer use: every gradient comes from p.grad
         self.gather_grads()
         self.advance_host()
         self.launch()

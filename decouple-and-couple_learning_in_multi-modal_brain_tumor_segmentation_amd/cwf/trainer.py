@@ -9,12 +9,13 @@ Execution modes:
   * graph: forward + losses + backward + gradient flattening are captured ONCE into a hipGraph (torch.cuda.graph) and replayed
     per step (host cost ~1 ms).  Shapes are static (fixed patch size, per-sample top-k of fixed k) and the token selection runs
     on device, so nothing in the step needs the host.  Currently slower end to end than eager (the captured branches overlap less).
-Multi-GPU gradient averaging (the only data-path collective):
-  * default: after backward the flat 67 MB gradient buffer is all-reduced in 4 chunks (a few large messages -- the right shape
-    for point-to-point xGMI links; ~1 ms on an 8-GPU ring, <3 % of the step), then the single fused Adam kernel runs.  Backward's
-    end synchronises every stream, so this is race-free with the multi-stream regions.
-  * overlap_comm=True: bucketed all-reduce launched from autograd hooks while backward is still running (cwf.parallel.GradSync);
-    the regions are then kept on one stream (gradients of one bucket would otherwise be produced on different streams).
+Gradients never exist as per-parameter tensors: backward kernels write them into ONE flat buffer laid out in backward-completion
+order (cwf.optim.GradSink; the conv weight gradients through one batched split-K reduce per phase), which the fused Adam launch reads.
+Multi-GPU gradient averaging (the only data-path collective) is overlapped with backward: the model fires a callback when backward
+has passed a cut point (decoder done / everything but the encoder done, ClsWiseFormer.grad_phases); the phase's contiguous slice
+(9.8 MB, then 43 MB) is all-reduced (RCCL, summed; Adam reads g / world) on a communication stream that waits for the producing
+streams -- the three region streams and the weight-gradient side stream stay in use -- while the encoder's backward (~7 ms) runs;
+only the last 14 MB slice is exposed.  Under graph replay the collective follows the replay (4 chunks of the flat buffer).
 Checkpoints use the reference layout {'epoch', 'state_dict' with 'module.' prefix, 'optim_dict'} (:248-253)."""
 from __future__ import annotations
 
@@ -22,7 +23,6 @@ import torch
 import torch.distributed as dist
 
 from .optim import FusedAdam, poly_lr
-from .parallel import GradSync
 
 
 def total_loss(outputs, target, edge):
@@ -40,55 +40,98 @@ def kernels_backend():
 
 
 class Trainer:
-    def __init__(self, model, lr=2e-4, weight_decay=1e-5, amsgrad=True, end_epoch=1000, bucket_mb=16.0, use_graph=False,
-                 graph_warmup=2, overlap_comm=False, wgrad_async=True):
+    def __init__(self, model, lr=2e-4, weight_decay=1e-5, amsgrad=True, end_epoch=1000, use_graph=False,
+                 graph_warmup=2, overlap_comm=True, wgrad_async=True):
         self.model = model
         self.init_lr, self.end_epoch = lr, end_epoch
-        self.opt = FusedAdam(model.parameters(), lr=lr, weight_decay=weight_decay, amsgrad=amsgrad)
+        phases = model.grad_phases() if hasattr(model, "grad_phases") else None
+        self.opt = FusedAdam(model.parameters(), lr=lr, weight_decay=weight_decay, amsgrad=amsgrad, phases=phases)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.opt.grad_scale = 1.0 / self.world          # the all-reduce SUMS; Adam reads g / world (the DDP average, train_no_amp.py:133)
         self.use_graph = use_graph
-        self.sync = None
-        # weight gradients on a side stream (they are leaves of backward; the data-gradient chain is its critical path): +3 %.
-        # Not with hook-driven bucketed all-reduce (the hooks would read .grad before the side stream is joined).
-        self.wgrad_async = bool(wgrad_async) and not overlap_comm and next(model.parameters()).is_cuda
-        if self.world > 1 and overlap_comm and not use_graph:
-            self.sync = GradSync(model.parameters(), bucket_mb=bucket_mb)
-            if hasattr(model, "parallel_regions"):
-                model.parallel_regions = False
+        self.cuda = next(model.parameters()).is_cuda
+        # weight gradients on a side stream (they are leaves of backward; the data-gradient chain is its critical path)
+        self.wgrad_async = bool(wgrad_async) and self.cuda
+        # all-reduce of a phase's slice as soon as backward has passed its cut point (not under graph capture)
+        self.overlap_comm = bool(overlap_comm) and self.world > 1 and not use_graph
+        self._comm_stream = torch.cuda.Stream() if (self.overlap_comm and self.cuda) else None
+        self._works = []
         if self.world > 1:
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, 0)
+        if hasattr(model, "phase_callback"):
+            model.phase_callback = self._phase_done
         self._graph = None
         self._static = None
         self._eager_steps = 0
         self._graph_warmup = graph_warmup
+        self._in_backward = False
 
     # ------------------------------------------------------------------------------------------------
+    def _phase_done(self, k):
+        """Backward has passed cut point k: every gradient of phase k has been produced (conv weight gradients as split-K slabs).
+        Reduce the slabs of the layers seen so far into the flat buffer (one launch) and, data-parallel, start the all-reduce of
+        the phase's contiguous slice on the communication stream while backward goes on."""
+        if not self._in_backward:
+            return
+        K = kernels_backend()
+        K.wgrad_flush()
+        if self.overlap_comm and not _capturing():
+            self._allreduce_chunk(k)
+
+    def _allreduce_chunk(self, k):
+        lo, hi = self.opt.sink.chunks[k]
+        if hi <= lo:
+            return
+        chunk = self.opt.flat_grad[lo:hi]
+        if self._comm_stream is not None:
+            K = kernels_backend()
+            cs = self._comm_stream
+            cs.wait_stream(torch.cuda.current_stream())          # coupler gradients (region streams are joined into this one by autograd)
+            for st in K._wg_stream.values():
+                cs.wait_stream(st)                               # the batched slab reduce of this phase
+            with torch.cuda.stream(cs):
+                self._works.append(dist.all_reduce(chunk, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(chunk, async_op=True))
+
     def _fwd_bwd(self, x, target, edge):
+        self.opt._ensure()
+        sink = self.opt.sink
+        sink.begin()
         outputs = self.model(x, None)
         loss, parts = total_loss(outputs, target, edge)
         self.opt.zero_grad(set_to_none=True)
-        K = kernels_backend() if self.wgrad_async else None
-        if K is not None:
-            K.wgrad_async = True
+        K = kernels_backend()
+        K.wgrad_async = self.wgrad_async
+        self._in_backward = True
         try:
-            loss.backward()
+            with sink:
+                loss.backward()
+                K.wgrad_flush()            # the last phase (encoder)
         finally:
-            if K is not None:
-                K.wgrad_async = False
+            self._in_backward = False
+            K.wgrad_async = False
+            if self.wgrad_async:
                 K.join_wgrad_stream()      # weight gradients were produced on the side stream
-        if self.sync is not None:
-            self.sync.finish()            # eager multi-GPU: bucketed all-reduce overlapped with backward
-        self.opt.gather_grads()
+        self.opt.gather_grads()            # parameters whose gradient came through autograd after all (none on the normal path)
+        if self.overlap_comm and not _capturing():
+            self._allreduce_chunk(len(sink.chunks) - 1)
         return loss.detach(), [p.detach() for p in parts]
 
-    def _allreduce_flat(self):
-        if self.world > 1 and self.sync is None:
-            flat = self.opt.flat_grad
-            works = [dist.all_reduce(c, async_op=True) for c in flat.chunk(4)]
+    def _finish_comm(self):
+        if self.world == 1:
+            return
+        if self.overlap_comm and self._graph is None:
+            for w in self._works:
+                w.wait()
+            self._works = []
+            if self._comm_stream is not None:
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
+        else:                              # graph replay (collectives are not captured): the whole flat buffer after the replay
+            works = [dist.all_reduce(c, async_op=True) for c in self.opt.flat_grad.chunk(4)]
             for w in works:
                 w.wait()
-            flat.div_(self.world)
 
     def _capture(self, x, target, edge):
         self._static = (x.clone(), target.clone(), edge.clone())
@@ -111,10 +154,14 @@ class Trainer:
         else:
             loss, parts = self._fwd_bwd(x, target, edge)
             self._eager_steps += 1
-        self._allreduce_flat()
+        self._finish_comm()
         self.opt.advance_host()
         self.opt.launch()
         return loss, parts
+
+
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
 
 def save_checkpoint(path, model, optimizer, epoch):

@@ -79,6 +79,33 @@ class ClsWiseFormer(nn.Module):
         self.aux = {}
         self.parallel_regions = True  # run the three sub-region pipelines on parallel HIP streams
         self._streams = None
+        self.phase_callback = None    # set by cwf.trainer.Trainer: called with k when backward has passed cut point k (grad_phases)
+
+    def grad_phases(self):
+        """Parameters grouped by WHEN their gradients are final during backward (the order of the Trainer's flat gradient buffer):
+        phase 0 the decoder (backward starts there), phase 1 everything between the decoder and the encoder (heads, both couplers,
+        the decoupler convs, sum_fusion), phase 2 the encoder and conv_64_to_32.  The cut points are the gradients of the decoder's
+        input (phase 0 done) and of the decouplers' inputs x23 / x4 (phase 1 done); forward registers hooks there when
+        `phase_callback` is set, so that a phase's slice can be reduced / all-reduced while backward continues."""
+        dec = list(self.decoder.parameters())
+        enc = list(self.Unet_list.parameters()) + list(self.conv_64_to_32.parameters())
+        skip = {id(p) for p in dec + enc}
+        mid = [p for p in self.parameters() if id(p) not in skip]
+        return [dec, mid, enc]
+
+    def _cut(self, t, k, need=1):
+        """register the phase-k cut on tensor t (phase complete after `need` such cuts have fired)"""
+        cb = self.phase_callback
+        if cb is None or not torch.is_grad_enabled() or not t.requires_grad:
+            return
+        state = self._cut_state.setdefault(k, [0, need])
+
+        def hook(g):
+            state[0] += 1
+            if state[0] == state[1]:
+                cb(k)
+            return None
+        t.register_hook(hook)
 
     # ------------------------------------------------------------------------------------------------
     def _coupler_cfg(self, tr, names):
@@ -119,6 +146,8 @@ class ClsWiseFormer(nn.Module):
         x1, x2, x3, x4 = self.Unet_list(x)
         x2d, _, x2 = self.conv_64_to_32(x2, carry=True)           # :284 (x2 goes on to the decoder through the carry alias)
         x23 = CF.cat_channels(x2d, x3)
+        self._cut(x23, 1, need=2)
+        self._cut(x4, 1, need=2)
 
         # The three sub-region pipelines are made of small, latency-bound kernels (16^3 / 32^3 grids, 129-token GEMMs):
         # each runs on its own HIP stream so they overlap (under hipGraph capture they become parallel branches).
@@ -160,6 +189,7 @@ class ClsWiseFormer(nn.Module):
             self.aux["fusion"] = f_idx
         xb = CF.tokens_to_window(fused, sem_size, self.item_feature_n, self.patch_size)
         xb, _ = self.sum_fusion(xb)                                   # :582
+        self._cut(xb, 0)
         if self.collect_aux:
             self.aux["bottleneck"] = xb
         return x1, x2, x3, xb, sup, edge, mid_sup, mid_edge
@@ -177,6 +207,7 @@ class ClsWiseFormer(nn.Module):
             raise ValueError("the patch must yield at least %d semantic tokens: D*H*W >= %d (got %dx%dx%d)"
                              % (self.top_num, self.top_num * 2048, d, h, w))
         self.aux = {}
+        self._cut_state = {}
         backend().begin_step(x.device)
         self._packer.refresh()
         xc = x.to(torch.float32).permute(0, 2, 3, 4, 1).contiguous()  # NDHWC

@@ -80,6 +80,10 @@ int cwf_wgrad_mfma(int op,
                    void* stream);
 int cwf_wgrad_reduce(const float* partial, int nsplit, int64_t slab_floats,
                      const int32_t* inv_map, float* dW, float* db, void* stream);
+/* every layer of a backward phase in one launch: table = DEVICE array of descriptors (same slab / inverse-map conventions as
+ * cwf_wgrad_reduce); dW / db may point into one flat gradient buffer */
+struct cwf_wgrad_reduce_desc { const float* partial; const int32_t* inv; float* dW; float* db; int64_t slab; int32_t nsplit; int32_t pad_; };
+int cwf_wgrad_reduce_batched(const struct cwf_wgrad_reduce_desc* table, int nlayers, void* stream);
 
 struct cwf_gather_desc { const float* src; float* dst; const int32_t* map; int64_t n; };
 
@@ -335,6 +339,10 @@ struct cwf_adam_desc { float* p; const float* g; float* m; float* v; float* vmax
 int cwf_adam_amsgrad(const struct cwf_adam_desc* table, int ntensors, int64_t max_n,
                      double lr, double beta1, double beta2, double eps, double weight_decay, int step, int amsgrad,
                      const float* hyper_dev, void* stream);
+/* the same with the gradient read as g * grad_scale (1 / world size: the summed all-reduce result becomes the average here) */
+int cwf_adam_amsgrad_scaled(const struct cwf_adam_desc* table, int ntensors, int64_t max_n,
+                            double lr, double beta1, double beta2, double eps, double weight_decay, int step, int amsgrad,
+                            const float* hyper_dev, float grad_scale, void* stream);
 /* hyper-parameters in double: torch derives step_size = lr/(1-beta1^t) and sqrt(1-beta2^t) in double.  hyper_dev
  * (nullable): device float[2] = {step_size, sqrt(1-beta2^t)} overriding the values derived from lr/step -- lets the
  * launch be captured in a hipGraph and replayed while the host advances the schedule.                                  */

@@ -466,8 +466,13 @@ class EmulBackend:
             out = out + torch.where((inv >= 0)[:, :, None], picked, torch.zeros_like(picked))
         return out
 
-    def head_grad(self, a1, c1, a2, c2):
-        return (a1 + c1).sum(0).reshape(1, 1, -1), (a2 + c2).sum(0).reshape(1, 1, -1)
+    def head_grad(self, a1, c1, a2, c2, out1=None, out2=None):
+        o1, o2 = (a1 + c1).sum(0).reshape(1, 1, -1), (a2 + c2).sum(0).reshape(1, 1, -1)
+        if out1 is not None:
+            out1.copy_(o1); o1 = out1
+        if out2 is not None:
+            out2.copy_(o2); o2 = out2
+        return o1, o2
 
     def add3(self, a, b, c):
         return (a + b) + c
@@ -546,7 +551,17 @@ class EmulBackend:
         return dls
 
     # ------------------------------------------------------------------ K11 / misc
-    def adam(self, table, ntensors, max_n, lr, beta1, beta2, eps, wd, step, amsgrad, hyper_dev=None):
+    def wgrad_to(self, key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec=None, allow_async=False):
+        """gradient-sink form of wgrad: the result lands in (dw_dst, db_dst) directly (the HIP backend defers the reduction)"""
+        gw, gb = self.wgrad(op, x, in_scale, in_shift, slope, dy, cout, inv_map, db_dst is not None, dw_dst.numel(), w_ref_shape=dw_dst.shape)
+        dw_dst.copy_(gw.view_as(dw_dst))
+        if db_dst is not None:
+            db_dst.copy_(gb)
+
+    def wgrad_flush(self, device=None):
+        pass
+
+    def adam(self, table, ntensors, max_n, lr, beta1, beta2, eps, wd, step, amsgrad, hyper_dev=None, grad_scale=1.0):
         """Pointer-table form of torch.optim.Adam(amsgrad, weight_decay) -- optim.hip / train_no_amp.py:136,239.  Host
         memory only (CPU tests): rows = [param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, n] raw addresses."""
         import ctypes
@@ -561,7 +576,7 @@ class EmulBackend:
             step_size, sqrt_bc2 = lr / (1.0 - beta1 ** step), math.sqrt(1.0 - beta2 ** step)
         for pp, gp, mp, vp, xp, n in table.tolist()[:ntensors]:
             p_, g_, m_, v_ = view(pp, n), view(gp, n), view(mp, n), view(vp, n)
-            g = g_ + wd * p_
+            g = g_ * grad_scale + wd * p_
             m_.mul_(beta1).add_(g, alpha=1.0 - beta1)
             v_.mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
             if amsgrad:

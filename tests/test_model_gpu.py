@@ -329,3 +329,43 @@ def test_graph_replay_matches_eager_step(hip):
         assert float((g1 - g2).norm() / g1.norm()) > 1e-3
     finally:
         kernels.set_precision("fp32")
+
+
+def test_gradient_sink_equals_plain_autograd(hip):
+    """Trainer path (gradients written by the backward kernels into the flat buffer: batched split-K reduce per backward phase,
+    coupler Functions writing their weight-set gradients in place, side-stream weight gradients) == plain `loss.backward()` of the
+    same model with per-parameter .grad tensors, to reduction-order noise (teacher-forced top-k, dropout off)."""
+    from cwf import kernels
+    from cwf.trainer import Trainer, total_loss
+    kernels.set_precision("bf16x3", wgrad="bf16", dgrad="bf16")
+    try:
+        xc, target, edge = syn.synthetic_batch([0], (64, 64, 64))
+        with torch.no_grad():
+            _, aux = rm.forward(syn.det_state_dict(rm.param_shapes()), xc, return_aux=True)
+        forced = {k: v.to(DEV) for k, v in aux.items() if v.dtype == torch.int64}
+        x, target, edge = xc.to(DEV), target.to(DEV), edge.to(DEV)
+        plain = []
+        for _ in range(2):
+            m = _no_dropout_model(forced)
+            loss, _ = total_loss(m(x, None), target, edge)
+            loss.backward()
+            plain.append({n: p.grad.clone() for n, p in m.named_parameters()})
+        noise = max(float((plain[0][n] - plain[1][n]).norm() / (plain[0][n].norm() + 1e-30)) for n in plain[0] if float(plain[0][n].norm()) > 1e-7)
+        m = _no_dropout_model(forced)
+        tr = Trainer(m)
+        for rep in range(2):                               # twice: the second step reuses the cached descriptor tables / slab buffers
+            tr._fwd_bwd(x, target, edge)
+            torch.cuda.synchronize()
+            assert all(p.grad is None for p in m.parameters())
+            names = {id(p): n for n, p in m.named_parameters()}
+            off = 0
+            for p in tr.opt.sink.params:
+                g = tr.opt.flat_grad[off:off + p.numel()].view_as(p)
+                off += p.numel()
+                ref = plain[0][names[id(p)]]
+                if float(ref.norm()) > 1e-7:
+                    d = float((g - ref).norm() / ref.norm())
+                    assert d < max(5e-5, 10 * noise), (names[id(p)], d, noise, rep)
+        assert [hi - lo for lo, hi in tr.opt.sink.chunks] == [sum(p.numel() for p in ph) for ph in m.grad_phases()]
+    finally:
+        kernels.set_precision("fp32")
