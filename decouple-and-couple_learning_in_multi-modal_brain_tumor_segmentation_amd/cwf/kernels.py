@@ -271,7 +271,7 @@ class HipBackend:
         slab = self.lib.cwf_wgrad_slab_floats(op, cin, cout)
         if nsplit <= 0 or slab <= 0 or slab != inv_map.numel():
             raise _lib.CwfError("cwf_wgrad plan failed (%d, %d, %d)" % (nsplit, slab, inv_map.numel()))
-        pk_ = (key, x.device, torch.cuda.is_current_stream_capturing())
+        pk_ = (key, x.device)                 # persistent, also across graph capture: the descriptor tables below stay valid
         part = self._wg_part.get(pk_)
         if part is None or part.numel() < nsplit * slab:
             part = torch.empty(int(nsplit * slab), dtype=_f32, device=x.device)
@@ -301,7 +301,15 @@ class HipBackend:
         if table is None:                       # static across steps (persistent buffers, static shapes): built once
             import struct
             raw = b"".join(struct.pack("<QQQQqii", r[0], r[1], r[2], r[3], r[4], r[5], 0) for r in rows)
-            table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+            host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+            if torch.cuda.is_current_stream_capturing():
+                # (only if no eager step preceded the capture) a pinned source keeps the copy capturable; it must outlive the graph
+                host = host.pin_memory()
+                self._wg_tables[("pinned",) + key] = host
+                table = torch.empty_like(host, device=device)
+                table.copy_(host, non_blocking=True)
+            else:
+                table = host.to(device)
             self._wg_tables[key] = table
         if self.wgrad_async:
             side = self.wgrad_stream(device)
