@@ -164,34 +164,48 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // reduce above launches slab/1024 workgroups -- 7..28 for most layers of this model -- and was latency-bound at ~36 us each,
 // 80 launches and 2.9 ms per step.  dW / db point straight into the flat gradient buffer the optimizer and the all-reduce use.
 __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const cwf_wgrad_reduce_desc* __restrict__ table) {
+  // 64 float4 columns x 4 split lanes per workgroup: a column's nsplit slabs are summed by four threads (k = lane, lane+4, ...,
+  // four loads in flight each) and combined through LDS in a fixed order -- the chain of dependent loads per column is
+  // nsplit/16 long instead of nsplit/4, and small slabs still fill a workgroup.
+  __shared__ float4 red[4][64];
   const cwf_wgrad_reduce_desc d = table[blockIdx.y];
   const int64_t stride4 = d.slab >> 2;
-  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < stride4; q += (int64_t)gridDim.x * blockDim.x) {
-    const float4* p = reinterpret_cast<const float4*>(d.partial) + q;
+  const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  for (int64_t q0 = (int64_t)blockIdx.x * 64; q0 < stride4; q0 += (int64_t)gridDim.x * 64) {
+    const int64_t q = q0 + c;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    int k = 0;
-    for (; k + 4 <= d.nsplit; k += 4) {
-      const float4 a0 = p[(int64_t)k * stride4], a1 = p[(int64_t)(k + 1) * stride4], a2 = p[(int64_t)(k + 2) * stride4], a3 = p[(int64_t)(k + 3) * stride4];
-      s.x += a0.x; s.y += a0.y; s.z += a0.z; s.w += a0.w;
-      s.x += a1.x; s.y += a1.y; s.z += a1.z; s.w += a1.w;
-      s.x += a2.x; s.y += a2.y; s.z += a2.z; s.w += a2.w;
-      s.x += a3.x; s.y += a3.y; s.z += a3.z; s.w += a3.w;
+    if (q < stride4) {
+      const float4* p = reinterpret_cast<const float4*>(d.partial) + q;
+      int k = sl;
+      for (; k + 12 < d.nsplit; k += 16) {
+        const float4 a0 = p[(int64_t)k * stride4], a1 = p[(int64_t)(k + 4) * stride4], a2 = p[(int64_t)(k + 8) * stride4], a3 = p[(int64_t)(k + 12) * stride4];
+        s.x += a0.x; s.y += a0.y; s.z += a0.z; s.w += a0.w;
+        s.x += a1.x; s.y += a1.y; s.z += a1.z; s.w += a1.w;
+        s.x += a2.x; s.y += a2.y; s.z += a2.z; s.w += a2.w;
+        s.x += a3.x; s.y += a3.y; s.z += a3.z; s.w += a3.w;
+      }
+      for (; k < d.nsplit; k += 4) { const float4 a0 = p[(int64_t)k * stride4]; s.x += a0.x; s.y += a0.y; s.z += a0.z; s.w += a0.w; }
     }
-    for (; k < d.nsplit; ++k) { const float4 a0 = p[(int64_t)k * stride4]; s.x += a0.x; s.y += a0.y; s.z += a0.z; s.w += a0.w; }
-    const int4 m = reinterpret_cast<const int4*>(d.inv)[q];
-    const int mm[4] = {m.x, m.y, m.z, m.w};
-    const float ss[4] = {s.x, s.y, s.z, s.w};
+    __syncthreads();
+    red[sl][c] = s;
+    __syncthreads();
+    if (sl == 0 && q < stride4) {
+      const float4 r0 = red[0][c], r1 = red[1][c], r2 = red[2][c], r3 = red[3][c];
+      const float ss[4] = {(r0.x + r1.x) + (r2.x + r3.x), (r0.y + r1.y) + (r2.y + r3.y), (r0.z + r1.z) + (r2.z + r3.z), (r0.w + r1.w) + (r2.w + r3.w)};
+      const int4 m = reinterpret_cast<const int4*>(d.inv)[q];
+      const int mm[4] = {m.x, m.y, m.z, m.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (mm[i] >= 0) d.dW[mm[i]] = ss[i];
-      else if (mm[i] <= -2 && d.db) d.db[-2 - mm[i]] = ss[i];
+      for (int i = 0; i < 4; ++i) {
+        if (mm[i] >= 0) d.dW[mm[i]] = ss[i];
+        else if (mm[i] <= -2 && d.db) d.db[-2 - mm[i]] = ss[i];
+      }
     }
   }
 }
 
 extern "C" int cwf_wgrad_reduce_batched(const struct cwf_wgrad_reduce_desc* table, int nlayers, void* stream) {
   if (!table || nlayers <= 0 || nlayers > 65535) return CWF_E_BADARG;
-  hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(32, nlayers), dim3(256), 0, cwf_stream(stream), table);
+  hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(128, nlayers), dim3(256), 0, cwf_stream(stream), table);
   CWF_LAUNCH_CHECK();
   return 0;
 }
