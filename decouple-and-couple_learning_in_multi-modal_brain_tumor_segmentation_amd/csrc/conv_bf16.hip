@@ -1307,6 +1307,7 @@ __global__ void gather_split_bf16_kernel(const cwf_gather_desc* __restrict__ tab
   unsigned short* dst = reinterpret_cast<unsigned short*>(d.dst);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * blockDim.x) {
     const int32_t m = d.map[i];
+    if (m == -2) continue;                       // owned by another source of a fused layer
     const float v = m >= 0 ? d.src[m] : 0.f;
     const __bf16 h = (__bf16)v;
     const __bf16 l = (__bf16)(v - (float)h);

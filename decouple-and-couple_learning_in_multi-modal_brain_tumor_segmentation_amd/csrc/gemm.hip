@@ -36,9 +36,12 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs a) {
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
   const int64_t a_zoff = zb * a.sa_zb + zh * a.sa_zh;
   const float* A = ((a.A2 && n0 >= a.split_n) ? a.A2 : a.A) + a_zoff;
-  const float* B = ((a.B2 && m0 >= a.split_m) ? a.B2 : a.B) + zb * a.sb_zb + zh * a.sb_zh;
+  const bool tabB = a.B_tab[0] != nullptr;
+  const float* B = tabB ? a.B_tab[blockIdx.z] : a.B + zb * a.sb_zb + zh * a.sb_zh;
+  if (a.B2 && m0 >= a.split_m) B = a.B2 + zb * a.sb_zb + zh * a.sb_zh;      // (B2 is an activation operand: strided also in the grouped form)
   const bool a_drop = a.a_drop_p > 0.f;
-  const bool do_rs = a.rowsum != nullptr && blockIdx.x == 0 && wc == 0;
+  float* rowsum = a.rowsum_tab[0] ? a.rowsum_tab[blockIdx.z] : a.rowsum;
+  const bool do_rs = rowsum != nullptr && blockIdx.x == 0 && wc == 0;
 
   f32x4 acc[IM][JN], accr[IM];
 #pragma unroll
@@ -106,8 +109,9 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs a) {
     }
   }
   const int64_t c_zoff = zb * a.sc_zb + zh * a.sc_zh;
-  float* C = a.C + c_zoff;
+  float* C = a.C_tab[0] ? a.C_tab[blockIdx.z] : a.C + c_zoff;
   float* C2 = a.C2 ? a.C2 + c_zoff : nullptr;
+  const float* bias = a.bias_tab[0] ? a.bias_tab[blockIdx.z] : a.bias;
   const float* R = a.residual ? a.residual + zb * a.sr_zb + zh * a.sr_zh : nullptr;
   const bool c_drop = a.c_drop_p > 0.f;
 #pragma unroll
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs a) {
     for (int j = 0; j < JN; ++j) {
       const int gn = n0 + wc * (TN / 2) + j * 16 + r;
       if (gn >= a.N) continue;
-      const float bv = a.bias ? a.bias[gn] : 0.f;
+      const float bv = bias ? bias[gn] : 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int gm = m0 + wr * (TM / 2) + i * 16 + kq * 4 + e;
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int gm = m0 + wr * (TM / 2) + i * 16 + kq * 4 + e;
-        if (gm < a.M) a.rowsum[gm] = (a.rowsum_acc ? a.rowsum[gm] : 0.f) + accr[i][e];
+        if (gm < a.M) rowsum[gm] = (a.rowsum_acc ? rowsum[gm] : 0.f) + accr[i][e];
       }
   }
 }
@@ -146,11 +150,14 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs a) {
 extern "C" int cwf_gemm_ex(const struct cwf_gemm_args* args, void* stream) {
   if (!args) return CWF_E_BADARG;
   const GemmArgs& a = *args;
-  if (!a.A || !a.B || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0 || a.ZB <= 0 || a.ZH <= 0) return CWF_E_BADARG;
+  if (!a.A || (!a.B && !a.B_tab[0]) || (!a.C && !a.C_tab[0]) || a.M <= 0 || a.N <= 0 || a.K <= 0 || a.ZB <= 0 || a.ZH <= 0) return CWF_E_BADARG;
+  if ((a.B_tab[0] || a.bias_tab[0] || a.C_tab[0] || a.rowsum_tab[0]) && (a.ZH != 1 || a.ZB > 4)) return CWF_E_BADARG;
   if ((int64_t)a.ZB * a.ZH > 65535) return CWF_E_TOOLARGE;
   if ((a.A2 && (a.split_n & 63)) || (a.B2 && (a.split_m & 63))) return CWF_E_BADARG;          // operand switch on a tile boundary
   if ((a.a_drop_p > 0.f || a.c_drop_p > 0.f) && !a.rng) return CWF_E_BADARG;
   if (a.rowsum && (int64_t)a.ZB * a.ZH != 1) return CWF_E_BADARG;
+  for (int z = 0; z < a.ZB && z < 4; ++z)
+    if ((a.B_tab[0] && !a.B_tab[z]) || (a.bias_tab[0] && !a.bias_tab[z]) || (a.C_tab[0] && !a.C_tab[z]) || (a.rowsum_tab[0] && !a.rowsum_tab[z])) return CWF_E_BADARG;
   const int64_t wg64 = (int64_t)cdiv(a.N, 64) * cdiv(a.M, 64) * a.ZB * a.ZH;
   if (wg64 >= 256) {
     dim3 grid(cdiv(a.N, 64), cdiv(a.M, 64), a.ZB * a.ZH);
@@ -381,17 +388,19 @@ extern "C" int cwf_colsum(const float* x, int64_t rows, int cols, int ld, float*
 // of the second problem reads x2[perm(r)], perm(r) = r with bit 0 of (r / perm_T) flipped.  One wave per (problem, row).
 __device__ __forceinline__ int ln_perm(int r, int perm_T) { return perm_T > 0 ? (((r / perm_T) ^ 1) * perm_T + r % perm_T) : r; }
 
+typedef struct cwf_ln_group_params LnGroups;
+
 template <int PER>
 __global__ __launch_bounds__(256) void ln_pair_fwd_kernel(const float* __restrict__ x, const float* __restrict__ x2, int perm_T,
-                                                         const float* __restrict__ g1, const float* __restrict__ b1,
-                                                         const float* __restrict__ g2, const float* __restrict__ b2,
+                                                         const LnGroups P, int rpg,
                                                          float* __restrict__ ya, float* __restrict__ yb, float* __restrict__ stats,
                                                          int rows, int E, float eps) {
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int prob = wid / rows, row = wid % rows;
   if (prob >= (x2 ? 2 : 1)) return;
   const float* xr = prob ? x2 + (int64_t)ln_perm(row, perm_T) * E : x + (int64_t)row * E;
-  const float* gamma = prob ? g2 : g1; const float* beta = prob ? b2 : b1;
+  const int grp = row / rpg;
+  const float* gamma = prob ? P.g2[grp] : P.g1[grp]; const float* beta = prob ? P.b2[grp] : P.b1[grp];
   float* y = (prob ? yb : ya) + (int64_t)row * E;
   float v[PER]; float s = 0.f;
 #pragma unroll
@@ -428,11 +437,12 @@ __device__ __forceinline__ void ln_bwd_row(float* o, const float* __restrict__ d
 template <int PER>
 __global__ __launch_bounds__(256) void ln_pair_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ da, const float* __restrict__ db,
                                                          const float* __restrict__ x, const float* __restrict__ x2, int perm_T,
-                                                         const float* __restrict__ g1, const float* __restrict__ g2, const float* __restrict__ stats,
+                                                         const LnGroups P, int rpg, const float* __restrict__ stats,
                                                          float* __restrict__ dx, float* __restrict__ dx2, int rows, int E) {
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int prob = wid / rows, row = wid % rows;
   if (prob >= (dx2 ? 2 : 1)) return;
+  const float* g1 = P.g1[row / rpg]; const float* g2 = P.g2[row / rpg];
   float v[PER], o[PER];
   const float* xr = (prob ? x2 : x) + (int64_t)row * E;
 #pragma unroll
@@ -462,16 +472,18 @@ __global__ __launch_bounds__(256) void ln_pair_bwd_kernel(const float* __restric
 // weight-sharing sum over the uses of one LayerNorm, ClsWiseTransformer.py:44-50)
 __global__ __launch_bounds__(1024) void ln_pair_params_kernel(const float* __restrict__ da, const float* __restrict__ db,
                                                              const float* __restrict__ x, const float* __restrict__ x2, int perm_T,
-                                                             const float* __restrict__ stats, float* __restrict__ dg1, float* __restrict__ db1,
-                                                             float* __restrict__ dg2, float* __restrict__ db2, int rows, int E, int accumulate) {
+                                                             const float* __restrict__ stats, const LnGroups P, int rpg,
+                                                             int rows_all, int E, int accumulate) {
   __shared__ float sg[16][64], sb[16][64];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, prob = blockIdx.y;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, prob = blockIdx.y, grp = blockIdx.z;
   const int c = blockIdx.x * 64 + lane;
   const float* d = prob ? db : da; const float* xs = prob ? x2 : x;
-  const float* st = stats + (int64_t)prob * rows * 2;
+  const float* st = stats + (int64_t)prob * rows_all * 2;
+  float* dg1 = P.dg1[grp]; float* db1 = P.db1[grp]; float* dg2 = P.dg2[grp]; float* db2 = P.db2[grp];
+  const int rbeg = grp * rpg, rows = rbeg + rpg;                 // this group's rows [rbeg, rows)
   float ag = 0.f, ab = 0.f;
   if (c < E) {
-    for (int row0 = w; row0 < rows; row0 += 64) {
+    for (int row0 = rbeg + w; row0 < rows; row0 += 64) {
       float dv[4], xv[4], mu[4], rs[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -507,12 +519,49 @@ __global__ __launch_bounds__(1024) void ln_pair_params_kernel(const float* __res
     else return CWF_E_BADARG;                                                                                                \
   } while (0)
 
+static int ln_groups_ok(const LnGroups* p, int groups, bool second, bool grads) {
+  if (!p || groups <= 0 || groups > 4) return 0;
+  for (int g = 0; g < groups; ++g) {
+    if (!p->g1[g] || (!p->b1[g] && !grads)) return 0;
+    if (second && (!p->g2[g] || (!grads && !p->b2[g]))) return 0;
+    if (grads && (!p->dg1[g] || !p->db1[g] || (second && (!p->dg2[g] || !p->db2[g])))) return 0;
+  }
+  return 1;
+}
+
+extern "C" int cwf_ln_pair_fwd_g(const float* x, const float* x2, int perm_T, const struct cwf_ln_group_params* h_params, int groups,
+                                 float* ya, float* yb, float* stats, int rows, int E, float eps, void* stream) {
+  if (!x || !ya || !stats || rows <= 0 || (x2 && !yb) || !ln_groups_ok(h_params, groups, x2 != nullptr, false) || rows % groups) return CWF_E_BADARG;
+  const int rpg = rows / groups;
+  if (perm_T > 0 && rpg % (2 * perm_T)) return CWF_E_BADARG;
+  const LnGroups P = *h_params;
+  dim3 grid(cdiv(rows * (x2 ? 2 : 1), 4));
+  LN_DISPATCH(ln_pair_fwd_kernel, grid, x, x2, perm_T, P, rpg, ya, yb, stats, rows, E, eps);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int cwf_ln_pair_fwd(const float* x, const float* x2, int perm_T, const float* g1, const float* b1, const float* g2, const float* b2,
                                float* ya, float* yb, float* stats, int rows, int E, float eps, void* stream) {
-  if (!x || !g1 || !b1 || !ya || !stats || rows <= 0 || (x2 && (!g2 || !b2 || !yb))) return CWF_E_BADARG;
-  if (perm_T > 0 && rows % (2 * perm_T)) return CWF_E_BADARG;
-  dim3 grid(cdiv(rows * (x2 ? 2 : 1), 4));
-  LN_DISPATCH(ln_pair_fwd_kernel, grid, x, x2, perm_T, g1, b1, g2, b2, ya, yb, stats, rows, E, eps);
+  LnGroups P = {};
+  P.g1[0] = g1; P.b1[0] = b1; P.g2[0] = g2; P.b2[0] = b2;
+  return cwf_ln_pair_fwd_g(x, x2, perm_T, &P, 1, ya, yb, stats, rows, E, eps, stream);
+}
+
+extern "C" int cwf_ln_pair_bwd_g(const float* dy, const float* da, const float* db, const float* x, const float* x2, int perm_T,
+                                 const struct cwf_ln_group_params* h_params, int groups, const float* stats, float* dx, float* dx2,
+                                 int rows, int E, int accumulate_params, void* stream) {
+  if (!da || !x || !stats || !dx || rows <= 0 || !ln_groups_ok(h_params, groups, db != nullptr, true) || rows % groups) return CWF_E_BADARG;
+  if (db && !x2) return CWF_E_BADARG;
+  if (dx2 && (!db || perm_T != 0)) return CWF_E_BADARG;
+  const int rpg = rows / groups;
+  if (perm_T > 0 && rpg % (2 * perm_T)) return CWF_E_BADARG;
+  if (E != 512 && E != 256 && E != 128 && E != 64) return CWF_E_BADARG;
+  const LnGroups P = *h_params;
+  hipLaunchKernelGGL(ln_pair_params_kernel, dim3(cdiv(E, 64), db ? 2 : 1, groups), dim3(1024), 0, cwf_stream(stream), da, db, x, x2, perm_T, stats,
+                     P, rpg, rows, E, accumulate_params);
+  dim3 grid(cdiv(rows * (dx2 ? 2 : 1), 4));
+  LN_DISPATCH(ln_pair_bwd_kernel, grid, dy, da, db, x, x2, perm_T, P, rpg, stats, dx, dx2, rows, E);
   CWF_LAUNCH_CHECK();
   return 0;
 }
@@ -520,17 +569,9 @@ extern "C" int cwf_ln_pair_fwd(const float* x, const float* x2, int perm_T, cons
 extern "C" int cwf_ln_pair_bwd(const float* dy, const float* da, const float* db, const float* x, const float* x2, int perm_T,
                                const float* g1, const float* g2, const float* stats, float* dx, float* dx2,
                                float* dg1, float* db1, float* dg2, float* db2, int rows, int E, int accumulate_params, void* stream) {
-  if (!da || !x || !g1 || !stats || !dx || !dg1 || !db1 || rows <= 0) return CWF_E_BADARG;
-  if (db && (!x2 || !g2 || !dg2 || !db2)) return CWF_E_BADARG;
-  if (dx2 && (!db || perm_T != 0)) return CWF_E_BADARG;
-  if (perm_T > 0 && rows % (2 * perm_T)) return CWF_E_BADARG;
-  if (E != 512 && E != 256 && E != 128 && E != 64) return CWF_E_BADARG;
-  hipLaunchKernelGGL(ln_pair_params_kernel, dim3(cdiv(E, 64), db ? 2 : 1), dim3(1024), 0, cwf_stream(stream), da, db, x, x2, perm_T, stats,
-                     dg1, db1, dg2, db2, rows, E, accumulate_params);
-  dim3 grid(cdiv(rows * (dx2 ? 2 : 1), 4));
-  LN_DISPATCH(ln_pair_bwd_kernel, grid, dy, da, db, x, x2, perm_T, g1, g2, stats, dx, dx2, rows, E);
-  CWF_LAUNCH_CHECK();
-  return 0;
+  LnGroups P = {};
+  P.g1[0] = g1; P.g2[0] = g2; P.dg1[0] = dg1; P.db1[0] = db1; P.dg2[0] = dg2; P.db2[0] = db2;
+  return cwf_ln_pair_bwd_g(dy, da, db, x, x2, perm_T, &P, 1, stats, dx, dx2, rows, E, accumulate_params, stream);
 }
 
 // dz = dh * keep(i) * gelu'(z): the backward of Dropout(GELU(z)) (FeedForward, ResidualNorm.py:40-43) with the mask recomputed

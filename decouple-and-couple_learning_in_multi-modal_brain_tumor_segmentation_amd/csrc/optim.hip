@@ -8,6 +8,7 @@ __global__ void gather_batched_kernel(const cwf_gather_desc* __restrict__ table)
   const cwf_gather_desc d = table[blockIdx.y];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * blockDim.x) {
     const int32_t m = d.map[i];
+    if (m == -2) continue;                       // owned by another source of a fused layer (three convs sharing one input)
     d.dst[i] = m >= 0 ? d.src[m] : 0.f;
   }
 }

@@ -339,7 +339,8 @@ __global__ __launch_bounds__(256) void index_inv_kernel(const int32_t* __restric
   }
 }
 
-struct GatherJob { const float* feats; const int32_t* index; const float* head; float* out; int64_t hbs, obs; int T; uint64_t drop_off; };
+struct GatherJob { const float* feats; const int32_t* index; const float* head; float* out; int64_t hbs, obs; int T; uint64_t drop_off;
+                   const float* head_g[4]; int group_B; };
 struct GatherArgs { GatherJob job[4]; int k, E; float pe_odd, p; const uint64_t* rng; };
 
 // out[b][0] = head ; out[b][1+j] = (feats[b][index[j]] + pe) * keep((b*k + j)*E + e)     grid (k+1, B, njobs), 128 threads
@@ -348,7 +349,8 @@ __global__ __launch_bounds__(128) void gather_multi_kernel(const GatherArgs a) {
   const int j = blockIdx.x, b = blockIdx.y, E = a.E, k = a.k;
   float* out = g.out + b * g.obs + (int64_t)j * E;
   if (j == 0) {
-    for (int e = threadIdx.x * 4; e < E; e += 512) *reinterpret_cast<float4*>(out + e) = *reinterpret_cast<const float4*>(g.head + b * g.hbs + e);
+    const float* hd = g.group_B > 0 ? g.head_g[b / g.group_B] : g.head + b * g.hbs;
+    for (int e = threadIdx.x * 4; e < E; e += 512) *reinterpret_cast<float4*>(out + e) = *reinterpret_cast<const float4*>(hd + e);
     return;
   }
   const int t = min(max(g.index[(int64_t)b * k + (j - 1)], 0), g.T - 1);
@@ -546,8 +548,13 @@ extern "C" int cwf_gather_multi(const struct cwf_gather_job* jobs, int njobs, in
   if (!jobs || njobs <= 0 || njobs > 4 || B <= 0 || k <= 0 || (E & 3) || (p > 0.f && !rng) || p < 0.f || p >= 1.f) return CWF_E_BADARG;
   GatherArgs a = {};
   for (int i = 0; i < njobs; ++i) {
-    if (!jobs[i].feats || !jobs[i].index || !jobs[i].head || !jobs[i].out || jobs[i].T <= 0) return CWF_E_BADARG;
-    a.job[i] = GatherJob{jobs[i].feats, jobs[i].index, jobs[i].head, jobs[i].out, jobs[i].head_bstride, jobs[i].out_bstride, jobs[i].T, jobs[i].drop_off};
+    if (!jobs[i].feats || !jobs[i].index || (!jobs[i].head && jobs[i].group_B <= 0) || !jobs[i].out || jobs[i].T <= 0) return CWF_E_BADARG;
+    a.job[i] = GatherJob{jobs[i].feats, jobs[i].index, jobs[i].head, jobs[i].out, jobs[i].head_bstride, jobs[i].out_bstride, jobs[i].T, jobs[i].drop_off,
+                         {jobs[i].head_g[0], jobs[i].head_g[1], jobs[i].head_g[2], jobs[i].head_g[3]}, jobs[i].group_B};
+    if (jobs[i].group_B > 0) {
+      if ((B + jobs[i].group_B - 1) / jobs[i].group_B > 4) return CWF_E_BADARG;
+      for (int gI = 0; gI < (B + jobs[i].group_B - 1) / jobs[i].group_B; ++gI) if (!jobs[i].head_g[gI]) return CWF_E_BADARG;
+    }
   }
   a.k = k; a.E = E; a.pe_odd = pe_odd; a.p = p; a.rng = rng;
   hipLaunchKernelGGL(gather_multi_kernel, dim3(k + 1, B, njobs), dim3(128), 0, cwf_stream(stream), a);
@@ -594,6 +601,125 @@ extern "C" int cwf_head_grad(const float* a1, const float* c1, const float* a2, 
                              float* out1, float* out2, int B, int E, void* stream) {
   if (!a1 || !c1 || !out1 || B <= 0 || E <= 0 || (a2 && (!c2 || !out2))) return CWF_E_BADARG;
   hipLaunchKernelGGL(head_grad_kernel, dim3(cdiv(E, 256), a2 ? 2 : 1), dim3(256), 0, cwf_stream(stream), a1, c1, a2, c2, bstride, out1, out2, B, E);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- grouped forms: the three sub-regions of a batch in one launch (sample b' = g * group_B + b) --------------------------------
+struct QTab { const float* q1[4]; const float* q2[4]; };
+__global__ __launch_bounds__(256) void token_scores2g_kernel(const float* __restrict__ feats, const QTab q, int group_B, float* __restrict__ s1,
+                                                            float* __restrict__ s2, int T, int E, int64_t rows) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int g = (int)(row / T) / group_B;
+  const float* f = feats + row * E; const float* qa = q.q1[g]; const float* qb = q.q2[g];
+  float a = 0.f, c = 0.f;
+  for (int e = lane * 4; e < E; e += 256) {
+    const float4 fv = *reinterpret_cast<const float4*>(f + e);
+    const float4 u = *reinterpret_cast<const float4*>(qa + e);
+    a += fv.x * u.x + fv.y * u.y + fv.z * u.z + fv.w * u.w;
+    if (qb) { const float4 w = *reinterpret_cast<const float4*>(qb + e); c += fv.x * w.x + fv.y * w.y + fv.z * w.z + fv.w * w.w; }
+  }
+  a = wave_sum(a);
+  if (qb) c = wave_sum(c);
+  if (lane == 0) { s1[row] = a; if (qb) s2[row] = c; }
+}
+
+extern "C" int cwf_token_scores2_g(const float* feats, const float* const* h_q1, const float* const* h_q2, int groups, int group_B,
+                                   float* s1, float* s2, int B, int T, int E, void* stream) {
+  if (!feats || !h_q1 || !s1 || groups <= 0 || groups > 4 || group_B <= 0 || B != groups * group_B || T <= 0 || (E & 3) || (h_q2 && !s2)) return CWF_E_BADARG;
+  QTab q = {};
+  for (int g = 0; g < groups; ++g) {
+    if (!h_q1[g] || (h_q2 && !h_q2[g])) return CWF_E_BADARG;
+    q.q1[g] = h_q1[g]; q.q2[g] = h_q2 ? h_q2[g] : nullptr;
+  }
+  const int64_t rows = (int64_t)B * T;
+  hipLaunchKernelGGL(token_scores2g_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, cwf_stream(stream), feats, q, group_B, s1, s2, T, E, rows);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+
+struct HeadGradTab { float* o1[4]; float* o2[4]; };
+__global__ void head_grad_g_kernel(const float* a1, const float* c1, const float* a2, const float* c2, int64_t bs, const HeadGradTab t, int group_B, int E) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int g = blockIdx.z;
+  const float* pa = blockIdx.y ? a2 : a1; const float* pc = blockIdx.y ? c2 : c1;
+  float s = 0.f;
+  for (int b = g * group_B; b < (g + 1) * group_B; ++b) s += pa[b * bs + e] + pc[b * bs + e];
+  (blockIdx.y ? t.o2[g] : t.o1[g])[e] = s;
+}
+extern "C" int cwf_head_grad_g(const float* a1, const float* c1, const float* a2, const float* c2, int64_t bstride,
+                               float* const* h_out1, float* const* h_out2, int groups, int group_B, int E, void* stream) {
+  if (!a1 || !c1 || !a2 || !c2 || !h_out1 || !h_out2 || groups <= 0 || groups > 4 || group_B <= 0 || E <= 0) return CWF_E_BADARG;
+  HeadGradTab t = {};
+  for (int g = 0; g < groups; ++g) { if (!h_out1[g] || !h_out2[g]) return CWF_E_BADARG; t.o1[g] = h_out1[g]; t.o2[g] = h_out2[g]; }
+  hipLaunchKernelGGL(head_grad_g_kernel, dim3(cdiv(E, 256), 2, groups), dim3(256), 0, cwf_stream(stream), a1, c1, a2, c2, bstride, t, group_B, E);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void window_to_tokens_g_kernel(const float* __restrict__ x, int x_ldc, float* __restrict__ tok, int B,
+                                          int D, int H, int W, int C, int p0, int p1, int p2, int64_t per_group, int64_t total) {
+  const int64_t idx0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over tok elements of all groups
+  if (idx0 >= total) return;
+  const int g = (int)(idx0 / per_group); const int64_t idx = idx0 % per_group;
+  const int E = C * p0 * p1 * p2;
+  const int T = (D / p0) * (H / p1) * (W / p2);
+  const int f = (int)(idx % E); const int64_t bt = idx / E;
+  const int t = (int)(bt % T); const int b = (int)(bt / T);
+  int ff = f; const int k = ff % p2; ff /= p2; const int j = ff % p1; ff /= p1; const int i = ff % p0; const int c = ff / p0;
+  int tt = t; const int tw = tt % (W / p2); tt /= (W / p2); const int th = tt % (H / p1); const int td = tt / (H / p1);
+  const int d = td * p0 + i, h = th * p1 + j, w = tw * p2 + k;
+  tok[idx0] = x[((((int64_t)b * D + d) * H + h) * W + w) * x_ldc + g * C + c];
+}
+__global__ void tokens_to_window_g_kernel(const float* __restrict__ tok, float* __restrict__ x, int x_ldc, int G, int B,
+                                          int D, int H, int W, int C, int p0, int p1, int p2, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over x elements (b,d,h,w,g,c)
+  if (idx >= total) return;
+  const int c = (int)(idx % C); int64_t v = idx / C;
+  const int g = (int)(v % G); v /= G;
+  const int w = (int)(v % W); v /= W; const int h = (int)(v % H); v /= H; const int d = (int)(v % D); const int b = (int)(v / D);
+  const int E = C * p0 * p1 * p2;
+  const int T = (D / p0) * (H / p1) * (W / p2);
+  const int t = ((d / p0) * (H / p1) + h / p1) * (W / p2) + w / p2;
+  const int f = ((c * p0 + d % p0) * p1 + h % p1) * p2 + w % p2;
+  x[((((int64_t)b * D + d) * H + h) * W + w) * x_ldc + g * C + c] = tok[(((int64_t)g * B + b) * T + t) * E + f];
+}
+extern "C" int cwf_window_to_tokens_g(const float* x, int x_ldc, float* tok, int groups, int B, int D, int H, int W, int C,
+                                      int p0, int p1, int p2, void* stream) {
+  if (!x || !tok || groups <= 0 || B <= 0 || D % p0 || H % p1 || W % p2 || x_ldc < groups * C) return CWF_E_BADARG;
+  const int64_t per = (int64_t)B * D * H * W * C, total = per * groups;
+  hipLaunchKernelGGL(window_to_tokens_g_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, cwf_stream(stream), x, x_ldc, tok, B, D, H, W, C, p0, p1, p2, per, total);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int cwf_tokens_to_window_g(const float* tok, float* x, int x_ldc, int groups, int B, int D, int H, int W, int C,
+                                      int p0, int p1, int p2, void* stream) {
+  if (!x || !tok || groups <= 0 || B <= 0 || D % p0 || H % p1 || W % p2 || x_ldc < groups * C) return CWF_E_BADARG;
+  const int64_t total = (int64_t)B * D * H * W * C * groups;
+  hipLaunchKernelGGL(tokens_to_window_g_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, cwf_stream(stream), tok, x, x_ldc, groups, B, D, H, W, C, p0, p1, p2, total);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void cat3_channels_kernel(const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ x2, float* __restrict__ y,
+                                     int C, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over float4s of y
+  if (idx >= total) return;
+  const int CQ = C >> 2;
+  const int cq = (int)(idx % CQ); int64_t v = idx / CQ;
+  const int g = (int)(v % 3); v /= 3;
+  const float* src = g == 0 ? x0 : (g == 1 ? x1 : x2);
+  float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (src) val = *reinterpret_cast<const float4*>(src + v * C + cq * 4);
+  *reinterpret_cast<float4*>(y + (v * 3 + g) * C + cq * 4) = val;
+}
+extern "C" int cwf_cat3_channels(const float* x0, const float* x1, const float* x2, float* y, int64_t nvox, int C, void* stream) {
+  if (!y || nvox <= 0 || C <= 0 || (C & 3)) return CWF_E_BADARG;
+  const int64_t total = nvox * 3 * (C >> 2);
+  hipLaunchKernelGGL(cat3_channels_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, cwf_stream(stream), x0, x1, x2, y, C, total);
   CWF_LAUNCH_CHECK();
   return 0;
 }

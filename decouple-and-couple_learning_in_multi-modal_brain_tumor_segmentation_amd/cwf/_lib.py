@@ -82,6 +82,13 @@ SIGNATURES = {
     "cwf_dice_ce_finalize_multi": [P, P, P, P, I, I, L, I, P],
     "cwf_head_loss_sums": [P, I, I, P, P, P, I, I, I, I, I, P],
     "cwf_head_loss_bwd": [P, I, I, P, P, P, P, P, I, P, I, I, I, I, I, P],
+    "cwf_ln_pair_fwd_g": [P, P, I, P, I, P, P, P, I, I, F, P],
+    "cwf_ln_pair_bwd_g": [P, P, P, P, P, I, P, I, P, P, P, I, I, I, P],
+    "cwf_token_scores2_g": [P, P, P, I, I, P, P, I, I, I, P],
+    "cwf_head_grad_g": [P, P, P, P, L, P, P, I, I, I, P],
+    "cwf_window_to_tokens_g": [P, I, P, I, I, I, I, I, I, I, I, I, P],
+    "cwf_tokens_to_window_g": [P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "cwf_cat3_channels": [P, P, P, P, L, I, P],
     "cwf_rng_advance": [P, P],
     "cwf_dropout_mask_rng": [P, L, F, F, P, U64, P],
 }
@@ -96,13 +103,19 @@ class GemmArgs(C.Structure):
                 ("M", I), ("N", I), ("K", I), ("ZB", I), ("ZH", I), ("alpha", F), ("act", I), ("accumulate", I),
                 ("A2", P), ("split_n", I), ("B2", P), ("split_m", I), ("C2", P), ("rowsum", P), ("rowsum_acc", I), ("rng", P),
                 ("a_drop_off", C.c_uint64), ("a_drop_n", C.c_uint64), ("a_drop_p", F), ("a_drop_p2", F),
-                ("c_drop_off", C.c_uint64), ("c_drop_n", C.c_uint64), ("c_drop_p", F), ("c_drop_p2", F)]
+                ("c_drop_off", C.c_uint64), ("c_drop_n", C.c_uint64), ("c_drop_p", F), ("c_drop_p2", F),
+                ("B_tab", P * 4), ("bias_tab", P * 4), ("C_tab", P * 4), ("rowsum_tab", P * 4)]
+
+
+class LnGroupParams(C.Structure):
+    """struct cwf_ln_group_params (include/cwf_hip.h)"""
+    _fields_ = [(n, P * 4) for n in ("g1", "b1", "g2", "b2", "dg1", "db1", "dg2", "db2")]
 
 
 class GatherJob(C.Structure):
     """struct cwf_gather_job (include/cwf_hip.h)"""
     _fields_ = [("feats", P), ("index", P), ("head", P), ("out", P), ("head_bstride", L), ("out_bstride", L), ("T", I),
-                ("drop_off", C.c_uint64)]
+                ("drop_off", C.c_uint64), ("head_g", P * 4), ("group_B", I)]
 RESTYPE_INT64 = {"cwf_wgrad_partial_floats", "cwf_wgrad_slab_floats"}
 
 _lib = None

@@ -33,10 +33,11 @@ _f32 = torch.float32
 
 
 class CouplerConfig:
-    """Static description of one coupler call (not a tensor argument of the Function)."""
+    """Static description of one coupler call (not a tensor argument of the Function).  `names`: per group, the keys of its
+    selections (4 for a region: edge, sem_supp, sem, edge_supp; 1 for the fusion) for teacher forcing / aux."""
 
-    def __init__(self, heads, k, training, p_select, p_attn, p_pre, p_ffn, forced=None, names=None):
-        self.heads, self.k, self.training = heads, k, training
+    def __init__(self, heads, k, training, p_select, p_attn, p_pre, p_ffn, forced=None, names=None, groups=1):
+        self.heads, self.k, self.training, self.groups = heads, k, training, groups
         self.p_select = p_select if training else 0.0
         self.p_attn = p_attn if training else 0.0          # attention-probability dropout AND the attention's output dropout
         self.p_pre = p_pre if training else 0.0            # PreNormDrop.dropout (acts on the same tensor, in sequence)
@@ -47,6 +48,9 @@ class CouplerConfig:
 
 # parameter order of a transformer weight set as the Functions take it
 #   0 ln1_w  1 ln1_b  2 ln2_w  3 ln2_b  4 out_w  5 out_b  6 qkv_w  7 ffn_ln_w  8 ffn_ln_b  9 w1  10 b1  11 w2  12 b2
+NP = 13
+
+
 def transformer_params(model):
     ca = model.cross_attention_list[0].fn
     ff = model.cross_ffn_list[0].fn
@@ -54,18 +58,24 @@ def transformer_params(model):
             ff.norm.weight, ff.norm.bias, ff.fn.net[0].weight, ff.fn.net[0].bias, ff.fn.net[3].weight, ff.fn.net[3].bias)
 
 
+def _by_param(flat, groups):
+    """[set_0 (13 tensors), set_1, ...] -> P with P[i] = [tensor i of set 0, of set 1, ...]  (what the grouped kernels take)"""
+    return [[flat[g * NP + i] for g in range(groups)] for i in range(NP)]
+
+
 def _grad_buffers(P):
-    """Destination of the weight-set gradients: slices of the Trainer's flat gradient buffer when a sink is active (the
-    Functions then return None for them: autograd never sees these gradients), fresh tensors otherwise."""
+    """Destination of parameter gradients (P: list of lists of parameters): slices of the Trainer's flat gradient buffer when
+    a sink is active (the Functions then return None for them: autograd never sees these gradients), fresh tensors otherwise."""
     from .optim import active_sink
     sink = active_sink()
     if sink is not None:
-        views = [sink.view(p) for p in P]
-        if all(v is not None for v in views):
-            for p in P:
-                sink.mark(p)
+        views = [[sink.view(p) for p in ps] for ps in P]
+        if all(v is not None for vs in views for v in vs):
+            for ps in P:
+                for p in ps:
+                    sink.mark(p)
             return views, True
-    return [torch.empty_like(p) for p in P], False
+    return [[torch.empty_like(p) for p in ps] for ps in P], False
 
 
 def _site(K, cfg_p, n):
@@ -74,6 +84,7 @@ def _site(K, cfg_p, n):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # one cross-attention block:  y = x + Drop_pre(Drop_attn(out_proj(Attn(LN1(x), LN2(x2')))))     (ResidualNorm.py:4-32)
+# (x: the rows of all groups stacked; P[i]: one tensor per group)
 # ---------------------------------------------------------------------------------------------------------------------
 def _ca_fwd(K, P, cfg, x, x2, perm_T, z, t):
     """x, x2: [rows, E] (x2 None = x itself).  Returns (y, saved)."""
@@ -93,14 +104,14 @@ def _ca_fwd(K, P, cfg, x, x2, perm_T, z, t):
 
 
 def _ca_bwd(K, P, G, cfg, saved, dy, first, dual):
-    """dy [rows, E] -> (dx, dx2).  G = gradient buffers of the weight set (written when `first`, accumulated otherwise)."""
+    """dy [rows, E] -> (dx, dx2).  G = gradient buffers of the weight sets (written when `first`, accumulated otherwise)."""
     x, x2, perm_T, a, b, stats, qkv, o, d_attn, d_out, z, t = saved
     e = x.shape[1]
     K.linear_wgrad(dy, o, G[4], G[5], accumulate=not first, drop=d_out)                       # d out_proj.weight / .bias
     d_o = K.linear_dgrad(dy, P[4], drop=d_out)
     dqkv = K.attn_bwd(qkv, d_o, z, t, cfg.heads, d_attn)
-    da = K.linear_dgrad(dqkv[:, :e], P[6][:e])
-    db = K.linear_dgrad(dqkv[:, e:], P[6][e:])
+    da = K.linear_dgrad(dqkv[:, :e], [w[:e] for w in P[6]])
+    db = K.linear_dgrad(dqkv[:, e:], [w[e:] for w in P[6]])
     K.linear_wgrad(dqkv, a, G[6], None, x2=b, split_m=e, accumulate=not first)                 # d qkv.weight = [dq^T a ; dkv^T b]
     return K.ln_pair_bwd(dy, da, db, x, x if x2 is None else x2, perm_T, P[0], P[2], stats, G[0], G[1], G[2], G[3],
                          accumulate=not first, want_dx2=dual)
@@ -112,7 +123,7 @@ def _ca_bwd(K, P, G, cfg, saved, dy, first, dual):
 def _ffn_fwd(K, P, cfg, x):
     rows, e = x.shape
     h0, _, stats = K.ln_pair_fwd(x, None, 0, P[7], P[8], None, None)
-    hid = P[9].shape[0]
+    hid = P[9][0].shape[0]
     zpre = torch.empty((rows, hid), dtype=_f32, device=x.device)
     h1 = torch.empty((rows, hid), dtype=_f32, device=x.device)
     d1 = (_site(K, cfg.p_ffn, rows * hid), cfg.p_ffn, 0.0) if cfg.p_ffn > 0 else None
@@ -134,94 +145,114 @@ def _ffn_bwd(K, P, G, saved, dy):
     return dx
 
 
-def _select(K, cfg, name0, name1, feats, q0, q1, k):
-    """Two selections of one token matrix (scored by q0 / q1) -> (idx0, inv0, idx1, inv1); teacher-forced sets override."""
+def _select(K, cfg, j0, j1, feats, q0, q1, k, bg):
+    """Two selections of one stacked token matrix [G*bg, T, E] (scored by the groups' q0 / q1) -> (idx0, inv0, idx1, inv1);
+    teacher-forced sets (cfg.forced[cfg.names[g][j]]) override a group's rows."""
     s0, s1 = K.token_scores2(feats, q0, q1)
     idx0, inv0, idx1, inv1 = K.topk_inv(s0, s1, k)
     t = feats.shape[1]
-    if name0 in cfg.forced:
-        idx0, inv0 = K.index_inv(cfg.forced[name0], t)
-    if name1 is not None and name1 in cfg.forced:
-        idx1, inv1 = K.index_inv(cfg.forced[name1], t)
+    for g, names in enumerate(cfg.names):
+        for j, idx, inv in ((j0, idx0, inv0), (j1, idx1, inv1)):
+            if j is not None and names[j] in cfg.forced:
+                fi, fv = K.index_inv(cfg.forced[names[j]], t)
+                idx[g * bg:(g + 1) * bg] = fi
+                inv[g * bg:(g + 1) * bg] = fv
     return idx0, inv0, idx1, inv1
 
 
 class RegionCouplerFn(torch.autograd.Function):
-    """(E [B,Te,512], S [B,Ts,512], e_tok, s_tok, 13 weights) -> (gated_e, gated_s, scat_s, sem_tok [B,1,512], 4 index sets).
-    cfg.names = (edge, sem_supp, sem, edge_supp) keys for teacher forcing / aux."""
+    """The Edge-supported Intra-region Couplers of ALL sub-regions in one pass (groups = 3: every launch covers the three regions;
+    their weight sets, class tokens and LayerNorm parameters reach the kernels as per-group pointer tables).
+
+    (E [G,B,Te,512], S [G,B,Ts,512], G e_tokens, G s_tokens, G x 13 weights)
+        -> (gated_e [G,B,Te,512], gated_s, scat_s [G,B,Ts,512], sem_tok [G,B,1,512], 4 index sets [G*B,k])
+    cfg.names[g] = (edge, sem_supp, sem, edge_supp) keys of group g for teacher forcing / aux."""
 
     @staticmethod
-    def forward(ctx, cfg, E, S, e_tok, s_tok, *P):
+    def forward(ctx, cfg, E, S, *flat):
         K = backend()
         ctx.set_materialize_grads(False)     # unused outputs arrive as None in backward, not as zero-filled tensors
+        G = cfg.groups
+        e_toks, s_toks = list(flat[:G]), list(flat[G:2 * G])
+        P = _by_param(flat[2 * G:], G)
         E, S = E.contiguous(), S.contiguous()
-        b, _, e = E.shape
-        k = min(cfg.k, S.shape[1], E.shape[1])
+        _, b, te, e = E.shape
+        ts = S.shape[2]
+        Ef, Sf = E.view(G * b, te, e), S.view(G * b, ts, e)
+        k = min(cfg.k, ts, te)
         t = k + 1
-        n_e, n_ss, n_s, n_es = cfg.names
-        qe, qs = e_tok.detach(), s_tok.detach()
-        idx_e, inv_e, idx_es, inv_es = _select(K, cfg, n_e, n_es, E, qe, qs, k)        # E scored by e_tok (primary) / by s_tok (supplement)
-        idx_se, inv_se, idx_s, inv_s = _select(K, cfg, n_ss, n_s, S, qe, qs, k)        # S scored by e_tok (supplement) / by s_tok (primary)
-        X1 = torch.empty((b, 2, t, e), dtype=_f32, device=E.device)                  # [edge_seq ; sem_seq]
-        X2 = torch.empty((b, 2, t, e), dtype=_f32, device=E.device)                  # [sem_supp ; edge_supp]
-        offs = [_site(K, cfg.p_select, b * k * e) for _ in range(4)]
-        K.gather_multi([(E, idx_e, e_tok, X1[:, 0], offs[0]), (S, idx_s, s_tok, X1[:, 1], offs[1]),
-                        (S, idx_se, s_tok, X2[:, 0], offs[2]), (E, idx_es, e_tok, X2[:, 1], offs[3])], k, e, p=cfg.p_select)
-        rows, z = b * 2 * t, b * 2
+        qe, qs = [q.detach() for q in e_toks], [q.detach() for q in s_toks]
+        idx_e, inv_e, idx_es, inv_es = _select(K, cfg, 0, 3, Ef, qe, qs, k, b)         # E scored by e_tok (primary) / by s_tok (supplement)
+        idx_se, inv_se, idx_s, inv_s = _select(K, cfg, 1, 2, Sf, qe, qs, k, b)         # S scored by e_tok (supplement) / by s_tok (primary)
+        gb = G * b
+        X1 = torch.empty((gb, 2, t, e), dtype=_f32, device=E.device)                  # [edge_seq ; sem_seq]
+        X2 = torch.empty((gb, 2, t, e), dtype=_f32, device=E.device)                  # [sem_supp ; edge_supp]
+        offs = [_site(K, cfg.p_select, gb * k * e) for _ in range(4)]
+        K.gather_multi([(Ef, idx_e, e_toks, X1[:, 0], offs[0]), (Sf, idx_s, s_toks, X1[:, 1], offs[1]),
+                        (Sf, idx_se, s_toks, X2[:, 0], offs[2]), (Ef, idx_es, e_toks, X2[:, 1], offs[3])], k, e, p=cfg.p_select)
+        rows, z = gb * 2 * t, gb * 2
         y1, sv1 = _ca_fwd(K, P, cfg, X1.view(rows, e), X2.view(rows, e), 0, z, t)      # a = CA(edge, sem'), b = CA(sem, edge')
         y2, sv2 = _ca_fwd(K, P, cfg, y1, None, t, z, t)                                 # CA(a, b), CA(b, a)
         r, sv3 = _ffn_fwd(K, P, cfg, y2)                                                # FFN(cat(result_edge, result_sem))
-        R = r.view(b, 2, t, e)
-        gated_e, _ = K.scatter_inv(E, inv_e, R[:, 0, 1:], R[:, 0, 0:1], want_gated=True, want_scat=False)
-        gated_s, scat_s = K.scatter_inv(S, inv_s, R[:, 1, 1:], R[:, 1, 0:1], want_gated=True, want_scat=True)
+        R = r.view(gb, 2, t, e)
+        gated_e, _ = K.scatter_inv(Ef, inv_e, R[:, 0, 1:], R[:, 0, 0:1], want_gated=True, want_scat=False)
+        gated_s, scat_s = K.scatter_inv(Sf, inv_s, R[:, 1, 1:], R[:, 1, 0:1], want_gated=True, want_scat=True)
         sem_tok = R[:, 1, 0:1]
         ctx.cfg, ctx.sv, ctx.offs, ctx.k = cfg, (sv1, sv2, sv3), offs, k
-        ctx.toks = (e_tok, s_tok)
-        ctx.save_for_backward(E, S, R, idx_e, inv_e, inv_es, idx_s, inv_s, inv_se, *P)
+        ctx.toks = (e_toks, s_toks)
+        ctx.save_for_backward(Ef, Sf, R, idx_e, inv_e, inv_es, idx_s, inv_s, inv_se, *flat[2 * G:])
         idx = (idx_e, idx_se, idx_s, idx_es)
         ctx.mark_non_differentiable(*idx)
-        return (gated_e, gated_s, scat_s, sem_tok) + idx
+        return (gated_e.view(G, b, te, e), gated_s.view(G, b, ts, e), scat_s.view(G, b, ts, e), sem_tok.reshape(G, b, 1, e)) + idx
 
     @staticmethod
     def backward(ctx, dgated_e, dgated_s, dscat_s, dsem_tok, *_):
         K = backend()
         cfg, (sv1, sv2, sv3), offs, k = ctx.cfg, ctx.sv, ctx.offs, ctx.k
-        E, S, R, idx_e, inv_e, inv_es, idx_s, inv_s, inv_se = ctx.saved_tensors[:9]
-        P = ctx.saved_tensors[9:]
-        b, _, t, e = R.shape
-        c = lambda g: None if g is None else g.contiguous()
-        dgated_e, dgated_s, dscat_s, dsem_tok = c(dgated_e), c(dgated_s), c(dscat_s), c(dsem_tok)
-        G, sunk = _grad_buffers(P)
+        G = cfg.groups
+        Ef, Sf, R, idx_e, inv_e, inv_es, idx_s, inv_s, inv_se = ctx.saved_tensors[:9]
+        P = _by_param(ctx.saved_tensors[9:], G)
+        gb, _, t, e = R.shape
+        te, ts = Ef.shape[1], Sf.shape[1]
+        c = lambda g, n: None if g is None else g.contiguous().view(gb, n, e)
+        dgated_e, dgated_s, dscat_s, dsem_tok = c(dgated_e, te), c(dgated_s, ts), c(dscat_s, ts), c(dsem_tok, 1)
+        Gw, sunk = _grad_buffers(P)
         dR = torch.empty_like(R)
-        K.scatter_bwd(dgated_e, None, E, inv_e, idx_e, R[:, 0, 1:], R[:, 0, 0:1], None, dR[:, 0, 1:], dR[:, 0, 0:1])
-        K.scatter_bwd(dgated_s, dscat_s, S, inv_s, idx_s, R[:, 1, 1:], R[:, 1, 0:1], dsem_tok, dR[:, 1, 1:], dR[:, 1, 0:1])
-        rows = b * 2 * t
-        dy2 = _ffn_bwd(K, P, G, sv3, dR.view(rows, e))
-        dy1, _ = _ca_bwd(K, P, G, cfg, sv2, dy2, first=True, dual=False)
-        dx1, dx2 = _ca_bwd(K, P, G, cfg, sv1, dy1, first=False, dual=True)
-        dX1, dX2 = dx1.view(b, 2, t, e), dx2.view(b, 2, t, e)
+        K.scatter_bwd(dgated_e, None, Ef, inv_e, idx_e, R[:, 0, 1:], R[:, 0, 0:1], None, dR[:, 0, 1:], dR[:, 0, 0:1])
+        K.scatter_bwd(dgated_s, dscat_s, Sf, inv_s, idx_s, R[:, 1, 1:], R[:, 1, 0:1], dsem_tok, dR[:, 1, 1:], dR[:, 1, 0:1])
+        rows = gb * 2 * t
+        dy2 = _ffn_bwd(K, P, Gw, sv3, dR.view(rows, e))
+        dy1, _ = _ca_bwd(K, P, Gw, cfg, sv2, dy2, first=True, dual=False)
+        dx1, dx2 = _ca_bwd(K, P, Gw, cfg, sv1, dy1, first=False, dual=True)
+        dX1, dX2 = dx1.view(gb, 2, t, e), dx2.view(gb, 2, t, e)
         dE = K.token_grad(dgated_e, None, R[:, 0, 0:1], inv_e, inv_es, dX1[:, 0], dX2[:, 1], k, cfg.p_select, offs[0], offs[3])
         dS = K.token_grad(dgated_s, dscat_s, R[:, 1, 0:1], inv_s, inv_se, dX1[:, 1], dX2[:, 0], k, cfg.p_select, offs[1], offs[2])
-        e_tok, s_tok = ctx.toks
-        (tk, tk_sunk) = _grad_buffers((e_tok, s_tok))
-        d_etok, d_stok = K.head_grad(dX1[:, 0, 0], dX2[:, 1, 0], dX1[:, 1, 0], dX2[:, 0, 0], out1=tk[0], out2=tk[1])
-        if tk_sunk:
-            d_etok = d_stok = None
-        return (None, dE, dS, d_etok, d_stok) + (tuple(G) if not sunk else (None,) * len(G))
+        e_toks, s_toks = ctx.toks
+        (tk, tk_sunk) = _grad_buffers([e_toks, s_toks])
+        K.head_grad(dX1[:, 0, 0], dX2[:, 1, 0], dX1[:, 1, 0], dX2[:, 0, 0], out1=tk[0], out2=tk[1])
+        b = gb // G
+        dtoks = ((None,) * (2 * G)) if tk_sunk else (tuple(tk[0]) + tuple(tk[1]))
+        dP = ((None,) * (NP * G)) if sunk else tuple(Gw[i][g] for g in range(G) for i in range(NP))
+        return (None, dE.view(G, b, te, e), dS.view(G, b, ts, e)) + dtoks + dP
 
 
 class FusionCouplerFn(torch.autograd.Function):
     """(feats [B,Ts,512], tok [B,1,512] per-sample class token, 13 weights) -> (fused = scatter * gate, index set)."""
 
     @staticmethod
-    def forward(ctx, cfg, feats, tok, *P):
+    def forward(ctx, cfg, feats, tok, *flat):
         K = backend()
         ctx.set_materialize_grads(False)
+        P = _by_param(flat, 1)
         feats, tok = feats.contiguous(), tok.contiguous()
         b, ts, e = feats.shape
         k = min(cfg.k, ts)
         t = k + 1
-        idx, inv, _, _ = _select(K, cfg, cfg.names[0], None, feats, tok.detach(), None, k)
+        s0, _ = K.token_scores2(feats, tok.detach(), None)
+        idx, inv, _, _ = K.topk_inv(s0, None, k)
+        name = cfg.names[0][0]
+        if name in cfg.forced:
+            idx, inv = K.index_inv(cfg.forced[name], ts)
         X = torch.empty((b, t, e), dtype=_f32, device=feats.device)
         off = _site(K, cfg.p_select, b * k * e)
         K.gather_multi([(feats, idx, tok, X, off)], k, e, p=cfg.p_select)
@@ -231,7 +262,7 @@ class FusionCouplerFn(torch.autograd.Function):
         R = r.view(b, t, e)
         fused, _ = K.scatter_inv(feats, inv, R[:, 1:], R[:, 0:1], want_gated=True, want_scat=False)
         ctx.cfg, ctx.sv, ctx.off, ctx.k = cfg, (sv1, sv2), off, k
-        ctx.save_for_backward(feats, R, idx, inv, *P)
+        ctx.save_for_backward(feats, R, idx, inv, *flat)
         ctx.mark_non_differentiable(idx)
         return fused, idx
 
@@ -240,17 +271,17 @@ class FusionCouplerFn(torch.autograd.Function):
         K = backend()
         cfg, (sv1, sv2), off, k = ctx.cfg, ctx.sv, ctx.off, ctx.k
         feats, R, idx, inv = ctx.saved_tensors[:4]
-        P = ctx.saved_tensors[4:]
+        P = _by_param(ctx.saved_tensors[4:], 1)
         b, t, e = R.shape
         dfused = dfused.contiguous()
-        G, sunk = _grad_buffers(P)
+        Gw, sunk = _grad_buffers(P)
         dR = torch.empty_like(R)
         K.scatter_bwd(dfused, None, feats, inv, idx, R[:, 1:], R[:, 0:1], None, dR[:, 1:], dR[:, 0:1])
-        dy1 = _ffn_bwd(K, P, G, sv2, dR.view(b * t, e))
-        dx, _ = _ca_bwd(K, P, G, cfg, sv1, dy1, first=True, dual=False)
+        dy1 = _ffn_bwd(K, P, Gw, sv2, dR.view(b * t, e))
+        dx, _ = _ca_bwd(K, P, Gw, cfg, sv1, dy1, first=True, dual=False)
         dX = dx.view(b, t, e)
         dfeats = K.token_grad(dfused, None, R[:, 0:1], inv, None, dX, None, k, cfg.p_select, off, 0)
-        return (None, dfeats, dX[:, 0:1]) + (tuple(G) if not sunk else (None,) * len(G))
+        return (None, dfeats, dX[:, 0:1]) + (((None,) * NP) if sunk else tuple(Gw[i][0] for i in range(NP)))
 
 
 class _Add3Fn(torch.autograd.Function):
@@ -265,3 +296,57 @@ class _Add3Fn(torch.autograd.Function):
 
 def add3(a, b, c):
     return _Add3Fn.apply(a, b, c)
+
+
+class _SplitChannels3Fn(torch.autograd.Function):
+    """[N,D,H,W,3C] -> three channel-slice VIEWS (no copy: the kernels take (pointer, channel stride)); the adjoint assembles the
+    three slice gradients with one launch (autograd's own slice backward would be three zero fills, three copies and two adds)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)
+        c = x.shape[-1] // 3
+        ctx.shape, ctx.dev = tuple(x.shape[:-1]) + (c,), x.device
+        return x[..., :c], x[..., c:2 * c], x[..., 2 * c:]
+
+    @staticmethod
+    def backward(ctx, d0, d1, d2):
+        return backend().cat3_channels([d0, d1, d2], ctx.shape, ctx.dev)
+
+
+def split_channels3(x):
+    return _SplitChannels3Fn.apply(x)
+
+
+class _WindowToTokensGFn(torch.autograd.Function):
+    """grouped convert_dim (cls_wise_former.py:15-23): the three sub-regions' token matrices [3,B,T,512] in one launch"""
+
+    @staticmethod
+    def forward(ctx, x, groups, patch):
+        ctx.patch, ctx.size, ctx.c = patch, tuple(x.shape[1:4]), x.shape[4] // groups
+        return backend().window_to_tokens_g(x, groups, patch)
+
+    @staticmethod
+    def backward(ctx, d):
+        return backend().tokens_to_window_g(d, ctx.size, ctx.c, ctx.patch), None, None
+
+
+class _TokensToWindowGFn(torch.autograd.Function):
+    """grouped split_dim (cls_wise_former.py:26-39)"""
+
+    @staticmethod
+    def forward(ctx, tok, size, channels, patch):
+        ctx.patch, ctx.groups = patch, tok.shape[0]
+        return backend().tokens_to_window_g(tok, size, channels, patch)
+
+    @staticmethod
+    def backward(ctx, d):
+        return backend().window_to_tokens_g(d, ctx.groups, ctx.patch), None, None, None
+
+
+def window_to_tokens_g(x, groups, patch):
+    return _WindowToTokensGFn.apply(x, groups, tuple(patch))
+
+
+def tokens_to_window_g(tok, size, channels, patch):
+    return _TokensToWindowGFn.apply(tok, tuple(size), channels, tuple(patch))

@@ -63,27 +63,81 @@ class ConvSpec:
         return self.wpk16_d if dgrad else self.wpk16_f
 
 
+class FusedConvSpec(ConvSpec):
+    """Three convolutions that read the SAME input (the sub-region decouplers conv_semantic_{1,2,4}: 256 -> 128 each, and
+    conv_mid_fea_{1,2,4}: 96 -> 32 each; cls_wise_former.py:157-204) as ONE conv with 3 x cout output channels: the input is
+    staged once instead of three times and the launch has three times the workgroups.  The parameters stay three separate
+    tensors (checkpoint layout): each source fills its own third of the packed operand (map value -2 = "not mine")."""
+
+    def __init__(self, op, cin, cout_each):
+        super().__init__(op, cin, 3 * cout_each)
+        self.cout_each = cout_each
+        taps = {pk.CONV3_S1: 27, pk.CONV3_S2: 27, pk.CONV1: 1}[op]
+        self.src_numel = cout_each * cin * taps
+
+        def split(m):
+            out = []
+            for g in range(3):
+                own = (m >= 0) & (m // self.src_numel == g)
+                mg = np.where(own, m - g * self.src_numel, -2).astype(np.int32)
+                if g == 0:
+                    mg = np.where(m == -1, -1, mg).astype(np.int32)      # the padding zeros are written once, by source 0
+                out.append(mg)
+            return out
+        self.np_parts = {k: split(getattr(self, k)) for k in ("np_fwd", "np_dgrad", "np_fwd16", "np_dgrad16")}
+        self.np_bias = [np.where(np.arange(3 * cout_each) // cout_each == g, np.arange(3 * cout_each) - g * cout_each, -2).astype(np.int32)
+                        for g in range(3)]
+        self.part_maps = None
+        self.bias_all = None
+
+    def to(self, device):
+        if self.dev == device:
+            return self
+        super().to(device)
+        t = lambda a: torch.from_numpy(a).to(device)
+        self.part_maps = {k: [t(m) for m in v] for k, v in self.np_parts.items()}
+        self.bias_maps = [t(m) for m in self.np_bias]
+        self.bias_all = torch.zeros(self.cout, dtype=torch.float32, device=device)
+        return self
+
+
 class WeightPacker:
     """Packs every conv weight into the MFMA B-operand layouts (forward + data-gradient forms) with ONE launch
     per step (cwf_gather_batched / cwf_gather_split_bf16 over a device-resident descriptor table)."""
 
     def __init__(self):
         self.items = []          # (spec, weight Parameter)
+        self.fused = []          # (FusedConvSpec, [3 weights], [3 biases])
         self._key = None
         self._tables = None
 
     def add(self, spec, weight):
         self.items.append((spec, weight))
 
+    def add_fused(self, spec, weights, biases):
+        self.fused.append((spec, list(weights), list(biases)))
+
     def refresh(self):
         if not self.items:
             return
         for spec, _ in self.items:
             spec.uses = 0
+        for spec, _, _ in self.fused:
+            spec.uses = 0
         dev = self.items[0][1].device
-        key = (dev, tuple(w.data_ptr() for _, w in self.items))
+        key = (dev, tuple(w.data_ptr() for _, w in self.items), tuple(t.data_ptr() for _, ws, bs in self.fused for t in ws + bs))
         if key != self._key:
-            r32, r16 = [], []
+            r32, r16, rb = [], [], []
+            for spec, ws, bs in self.fused:
+                spec.to(dev)
+                for g, (w, b) in enumerate(zip(ws, bs)):
+                    assert w.is_contiguous() and b.is_contiguous()
+                    pm = spec.part_maps
+                    r32.append([w.data_ptr(), spec.wpk_f.data_ptr(), pm["np_fwd"][g].data_ptr(), pm["np_fwd"][g].numel()])
+                    r32.append([w.data_ptr(), spec.wpk_d.data_ptr(), pm["np_dgrad"][g].data_ptr(), pm["np_dgrad"][g].numel()])
+                    r16.append([w.data_ptr(), spec.wpk16_f.data_ptr(), pm["np_fwd16"][g].data_ptr(), pm["np_fwd16"][g].numel()])
+                    r16.append([w.data_ptr(), spec.wpk16_d.data_ptr(), pm["np_dgrad16"][g].data_ptr(), pm["np_dgrad16"][g].numel()])
+                    rb.append([b.data_ptr(), spec.bias_all.data_ptr(), spec.bias_maps[g].data_ptr(), spec.bias_maps[g].numel()])
             for spec, w in self.items:
                 spec.to(dev)
                 assert w.is_contiguous()
@@ -92,11 +146,15 @@ class WeightPacker:
                 r16.append([w.data_ptr(), spec.wpk16_f.data_ptr(), spec.fwd_map16.data_ptr(), spec.fwd_map16.numel()])
                 r16.append([w.data_ptr(), spec.wpk16_d.data_ptr(), spec.dgrad_map16.data_ptr(), spec.dgrad_map16.numel()])
             self._tables = {"fp32": (torch.tensor(r32, dtype=torch.int64).to(dev), max(r[3] for r in r32)),
-                            "bf16": (torch.tensor(r16, dtype=torch.int64).to(dev), max(r[3] for r in r16))}
+                            "bf16": (torch.tensor(r16, dtype=torch.int64).to(dev), max(r[3] for r in r16)),
+                            "bias": (torch.tensor(rb, dtype=torch.int64).to(dev), max(r[3] for r in rb)) if rb else None}
             self._key = key
         kind = "fp32" if precision() == "fp32" else "bf16"
         table, max_n = self._tables[kind]
         backend().gather_batched(table, table.shape[0], max_n, split_bf16=(kind == "bf16"))
+        if self._tables["bias"] is not None:      # the fused layers' concatenated biases (fp32 gather in every mode)
+            table, max_n = self._tables["bias"]
+            backend().gather_batched(table, table.shape[0], max_n, split_bf16=False)
 
 
 # ======================================================================================================
@@ -180,6 +238,63 @@ class _ConvFn(torch.autograd.Function):
         elif dcarry is not None:
             dx = dcarry
         return dx, dw, db, None, None, None, None, dres, None, None, None
+
+
+class _FusedConvFn(torch.autograd.Function):
+    """y[..., g*c:(g+1)*c] = conv(x; w_g) + b_g for the three same-input convs of a FusedConvSpec, + InstanceNorm statistics."""
+
+    @staticmethod
+    def forward(ctx, x, w0, w1, w2, b0, b1, b2, spec):
+        K = backend()
+        ctx.set_materialize_grads(False)
+        spec.uses += 1
+        emul = getattr(K, "name", "") == "emul"
+        w_ref = torch.cat((w0, w1, w2), 0) if emul else None
+        bias = torch.cat((b0, b1, b2), 0) if emul else spec.bias_all
+        stats = K.new_stats(x.shape[0], spec.cout, x.device)
+        y = K.conv(spec.op, x, spec.packed(False), bias, spec.cout, None, None, 1.0, None, None, stats, w_ref=w_ref)
+        sc, sh = K.in_finalize(stats, y.shape[1] * y.shape[2] * y.shape[3])
+        ctx.mark_non_differentiable(sc, sh)
+        ctx.spec = spec
+        ctx.params = (w0, w1, w2, b0, b1, b2)
+        ctx.save_for_backward(x)
+        return y, sc, sh
+
+    @staticmethod
+    def backward(ctx, dy, _a, _b):
+        K = backend()
+        (x,) = ctx.saved_tensors
+        spec = ctx.spec
+        w0, w1, w2, b0, b1, b2 = ctx.params
+        dy = dy.contiguous()
+        sink = active_sink()
+        views = [sink.view(t) for t in ctx.params] if (sink is not None and spec.uses <= 1) else None
+        adjacent = views is not None and all(v is not None for v in views) and \
+            views[1].data_ptr() == views[0].data_ptr() + 4 * w0.numel() and views[2].data_ptr() == views[1].data_ptr() + 4 * w1.numel() and \
+            views[4].data_ptr() == views[3].data_ptr() + 4 * b0.numel() and views[5].data_ptr() == views[4].data_ptr() + 4 * b1.numel()
+        grads = (None,) * 6
+        if adjacent:           # the three weight (bias) gradients are adjacent slices of the flat buffer: one reduce target each
+            K.wgrad_to(spec, spec.op, x, None, None, 1.0, dy, spec.cout, spec.inv_map, views[0], views[3], allow_async=True)
+            for t in ctx.params:
+                sink.mark(t)
+        else:
+            n = w0.numel()
+            dwf, db = K.wgrad(spec.op, x, None, None, 1.0, dy, spec.cout, spec.inv_map, True, 3 * n,
+                              w_ref_shape=(spec.cout,) + tuple(w0.shape[1:]), allow_async=False)
+            c = spec.cout_each
+            grads = (dwf[:n].view_as(w0), dwf[n:2 * n].view_as(w1), dwf[2 * n:].view_as(w2), db[:c], db[c:2 * c], db[2 * c:])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w_ref = torch.cat((w0, w1, w2), 0) if getattr(K, "name", "") == "emul" else None
+            dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dx, w_ref=w_ref, fwd_op=spec.op)
+        return (dx,) + grads + (None,)
+
+
+def fused_conv3(x, convs, spec):
+    """convs: three HipConv-like parameter holders (.weight, .bias) sharing the input x.  Returns (y [N,D,H,W,3*cout], (scale, shift))."""
+    y, sc, sh = _FusedConvFn.apply(x, convs[0].weight, convs[1].weight, convs[2].weight, convs[0].bias, convs[1].bias, convs[2].bias, spec)
+    return y, (sc, sh)
 
 
 def conv(x, w, b, spec, in_norm=None, slope=1.0, residual=None, out_scale=None, want_stats=False, carry=False):

@@ -39,6 +39,24 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+def _tab(ts):
+    """pointer table (up to 4 groups) for the grouped kernel forms"""
+    return (ctypes.c_void_p * 4)(*([t.data_ptr() for t in ts] + [0] * (4 - len(ts))))
+
+
+def _ln_params(**kw):
+    """struct cwf_ln_group_params from tensors or lists of tensors; returns (struct, groups)"""
+    P = _lib.LnGroupParams()
+    G = 1
+    for name, v in kw.items():
+        if v is None:
+            continue
+        vs = v if isinstance(v, (list, tuple)) else [v]
+        G = max(G, len(vs))
+        setattr(P, name, _tab(vs))
+    return P, G
+
+
 # Arithmetic of the conv family (forward, data gradient, weight gradient).  Activations / weights are fp32 in HBM in
 # every mode; the mode selects the MFMA operand form:
 #   "fp32"   v_mfma_f32_16x16x4_f32, exact f32 (the parity reference mode)
@@ -464,6 +482,34 @@ class HipBackend:
         self._call("cwf_tokens_to_window", tok.data_ptr(), x.data_ptr(), channels, b, d, h, w, channels, p0, p1, p2, 0, self._stream())
         return x
 
+    def window_to_tokens_g(self, x, groups, patch):
+        """x [B,D,H,W,groups*C] -> tok [groups,B,T,C*p0*p1*p2] (one launch for the three sub-regions)"""
+        x, ldc = cl(x)
+        b, d, h, w, ct = x.shape
+        c = ct // groups
+        p0, p1, p2 = patch
+        tok = torch.empty((groups, b, (d // p0) * (h // p1) * (w // p2), c * p0 * p1 * p2), dtype=_f32, device=x.device)
+        self._call("cwf_window_to_tokens_g", x.data_ptr(), ldc, tok.data_ptr(), groups, b, d, h, w, c, p0, p1, p2, self._stream())
+        return tok
+
+    def tokens_to_window_g(self, tok, size, channels, patch):
+        """tok [groups,B,T,E] -> x [B,D,H,W,groups*channels]"""
+        g, b = tok.shape[0], tok.shape[1]
+        d, h, w = size
+        p0, p1, p2 = patch
+        tok = tok.contiguous()
+        x = torch.empty((b, d, h, w, g * channels), dtype=_f32, device=tok.device)
+        self._call("cwf_tokens_to_window_g", tok.data_ptr(), x.data_ptr(), g * channels, g, b, d, h, w, channels, p0, p1, p2, self._stream())
+        return x
+
+    def cat3_channels(self, parts, shape, device):
+        """[N,D,H,W,C] x 3 (None = zeros) -> [N,D,H,W,3C]"""
+        n, d, h, w, c = shape
+        parts = [None if t is None else t.contiguous() for t in parts]
+        y = torch.empty((n, d, h, w, 3 * c), dtype=_f32, device=device)
+        self._call("cwf_cat3_channels", _p(parts[0]), _p(parts[1]), _p(parts[2]), y.data_ptr(), n * d * h * w, c, self._stream())
+        return y
+
     def token_scores(self, feats, query):
         """feats [B,T,E]; query [1,1,E] (shared) or [B,1,E]."""
         b, t, e = feats.shape
@@ -535,10 +581,20 @@ class HipBackend:
     def linear_fwd(self, x, w, bias, out, x2=None, split_n=0, act=0, pre=None, drop=None, residual=None):
         """out = drop(act(x' w^T + bias)) + residual ; x' = x for output columns < split_n, x2 beyond (2-D row-major views)."""
         m, k = x.shape
-        n = w.shape[0]
-        assert x.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1 and out.shape == (m, n)
-        kw = dict(A=x.data_ptr(), sa_m=x.stride(0), sa_k=1, B=w.data_ptr(), sb_k=1, sb_n=w.stride(0), C=out.data_ptr(), sc_m=out.stride(0),
-                  bias=_p(bias), M=m, N=n, K=k, ZB=1, ZH=1, alpha=1.0, act=act)
+        grouped = isinstance(w, (list, tuple))          # G weight sets: rows of x / out are G stacked problems (z = group)
+        G = len(w) if grouped else 1
+        w0 = w[0] if grouped else w
+        n = w0.shape[0]
+        assert x.stride(1) == 1 and w0.stride(1) == 1 and out.stride(1) == 1 and out.shape == (m, n) and m % G == 0
+        mg = m // G
+        kw = dict(A=x.data_ptr(), sa_m=x.stride(0), sa_k=1, sa_zb=mg * x.stride(0), B=w0.data_ptr(), sb_k=1, sb_n=w0.stride(0),
+                  C=out.data_ptr(), sc_m=out.stride(0), sc_zb=mg * out.stride(0), bias=_p(bias) if not grouped else 0,
+                  M=mg, N=n, K=k, ZB=G, ZH=1, alpha=1.0, act=act)
+        if grouped:
+            assert all(t.stride() == w0.stride() for t in w)
+            kw["B_tab"] = _tab(w)
+            if bias is not None:
+                kw["bias_tab"] = _tab(bias)
         if x2 is not None:
             assert x2.stride() == x.stride() and x2.shape == x.shape
             kw.update(A2=x2.data_ptr(), split_n=split_n)
@@ -547,7 +603,7 @@ class HipBackend:
             kw["C2"] = pre.data_ptr()
         if residual is not None:
             assert residual.stride(1) == 1
-            kw.update(residual=residual.data_ptr(), sr_m=residual.stride(0))
+            kw.update(residual=residual.data_ptr(), sr_m=residual.stride(0), sr_zb=mg * residual.stride(0))
         kw.update(self._drop_kw("c_drop", drop, m * n, x.device))
         if drop:
             assert out.stride(0) == n           # the mask index is the element offset inside out
@@ -557,11 +613,18 @@ class HipBackend:
     def linear_dgrad(self, dy, w, drop=None, out=None):
         """dx = (dy * keep) w ; dy [M,N] (row stride from the view), w [N,K] view."""
         m, n = dy.shape
-        k = w.shape[1]
-        assert dy.stride(1) == 1 and w.stride(1) == 1
+        grouped = isinstance(w, (list, tuple))
+        G = len(w) if grouped else 1
+        w0 = w[0] if grouped else w
+        k = w0.shape[1]
+        assert dy.stride(1) == 1 and w0.stride(1) == 1 and m % G == 0
+        mg = m // G
         dx = out if out is not None else torch.empty((m, k), dtype=_f32, device=dy.device)
-        kw = dict(A=dy.data_ptr(), sa_m=dy.stride(0), sa_k=1, B=w.data_ptr(), sb_k=w.stride(0), sb_n=1, C=dx.data_ptr(), sc_m=dx.stride(0),
-                  M=m, N=k, K=n, ZB=1, ZH=1, alpha=1.0)
+        kw = dict(A=dy.data_ptr(), sa_m=dy.stride(0), sa_k=1, sa_zb=mg * dy.stride(0), B=w0.data_ptr(), sb_k=w0.stride(0), sb_n=1,
+                  C=dx.data_ptr(), sc_m=dx.stride(0), sc_zb=mg * dx.stride(0), M=mg, N=k, K=n, ZB=G, ZH=1, alpha=1.0)
+        if grouped:
+            assert all(t.stride() == w0.stride() for t in w)
+            kw["B_tab"] = _tab(w)
         kw.update(self._drop_kw("a_drop", drop, m * n, dy.device))
         if drop:
             assert dy.stride(0) == n
@@ -572,25 +635,37 @@ class HipBackend:
         """dw (+)= (dy * keep)^T x' ; dbias (+)= column sums of dy * keep ; x' = x for dw rows < split_m, x2 beyond."""
         m, n = dy.shape
         k = x.shape[1]
-        assert dy.stride(1) == 1 and x.stride(1) == 1 and dw.shape == (n, k) and dw.is_contiguous()
-        kw = dict(A=dy.data_ptr(), sa_m=1, sa_k=dy.stride(0), B=x.data_ptr(), sb_k=x.stride(0), sb_n=1, C=dw.data_ptr(), sc_m=k,
-                  M=n, N=k, K=m, ZB=1, ZH=1, alpha=1.0, accumulate=int(accumulate))
+        grouped = isinstance(dw, (list, tuple))
+        G = len(dw) if grouped else 1
+        dw0 = dw[0] if grouped else dw
+        assert dy.stride(1) == 1 and x.stride(1) == 1 and dw0.shape == (n, k) and dw0.is_contiguous() and m % G == 0
+        mg = m // G
+        kw = dict(A=dy.data_ptr(), sa_m=1, sa_k=dy.stride(0), sa_zb=mg * dy.stride(0), B=x.data_ptr(), sb_k=x.stride(0), sb_n=1,
+                  sb_zb=mg * x.stride(0), C=dw0.data_ptr(), sc_m=k, M=n, N=k, K=mg, ZB=G, ZH=1, alpha=1.0, accumulate=int(accumulate))
+        if grouped:
+            assert all(t.shape == dw0.shape and t.is_contiguous() for t in dw)
+            kw["C_tab"] = _tab(dw)
         if x2 is not None:
             assert x2.stride() == x.stride()
             kw.update(B2=x2.data_ptr(), split_m=split_m)
         if dbias is not None:
-            kw.update(rowsum=dbias.data_ptr(), rowsum_acc=int(accumulate))
+            if grouped:
+                kw.update(rowsum_tab=_tab(dbias), rowsum_acc=int(accumulate))
+            else:
+                kw.update(rowsum=dbias.data_ptr(), rowsum_acc=int(accumulate))
         kw.update(self._drop_kw("a_drop", drop, m * n, dy.device))
         if drop:
             assert dy.stride(0) == n
         self._gemm_ex(**kw)
 
     def ln_pair_fwd(self, x, x2, perm_T, g1, b1, g2, b2, eps=1e-5):
+        """g1 ... b2: tensors, or lists of G tensors (rows = G stacked problems, one LayerNorm parameter set each)"""
         rows, e = x.shape
         ya = torch.empty_like(x)
         yb = torch.empty_like(x) if x2 is not None else None
         stats = torch.empty((2 if x2 is not None else 1, rows, 2), dtype=_f32, device=x.device)
-        self._call("cwf_ln_pair_fwd", x.data_ptr(), _p(x2), perm_T, g1.data_ptr(), b1.data_ptr(), _p(g2), _p(b2), ya.data_ptr(), _p(yb),
+        P, G = _ln_params(g1=g1, b1=b1, g2=g2, b2=b2)
+        self._call("cwf_ln_pair_fwd_g", x.data_ptr(), _p(x2), perm_T, ctypes.addressof(P), G, ya.data_ptr(), _p(yb),
                    stats.data_ptr(), rows, e, eps, self._stream())
         return ya, yb, stats
 
@@ -598,8 +673,9 @@ class HipBackend:
         rows, e = x.shape
         dx = torch.empty_like(x)
         dx2 = torch.empty_like(x) if want_dx2 else None
-        self._call("cwf_ln_pair_bwd", _p(dy), da.data_ptr(), _p(db), x.data_ptr(), _p(x2), perm_T, g1.data_ptr(), _p(g2), stats.data_ptr(),
-                   dx.data_ptr(), _p(dx2), dg1.data_ptr(), db1.data_ptr(), _p(dg2), _p(db2), rows, e, int(accumulate), self._stream())
+        P, G = _ln_params(g1=g1, g2=g2, dg1=dg1, db1=db1, dg2=dg2, db2=db2)
+        self._call("cwf_ln_pair_bwd_g", _p(dy), da.data_ptr(), _p(db), x.data_ptr(), _p(x2), perm_T, ctypes.addressof(P), G, stats.data_ptr(),
+                   dx.data_ptr(), _p(dx2), rows, e, int(accumulate), self._stream())
         return dx, dx2
 
     def attn_fwd(self, qkv, z, t, heads, drop=None):
@@ -627,9 +703,17 @@ class HipBackend:
 
     # ------------------------------------------------------------------ K4/K5, round-2 forms
     def token_scores2(self, feats, q1, q2=None):
+        """q1 / q2: [1|B,1,E] tensors, or lists of G shared queries (sample b belongs to group b // (B/G))"""
         b, t, e = feats.shape
         s1 = torch.empty((b, t), dtype=_f32, device=feats.device)
         s2 = torch.empty((b, t), dtype=_f32, device=feats.device) if q2 is not None else None
+        if isinstance(q1, (list, tuple)):
+            G = len(q1)
+            t1 = (ctypes.c_void_p * G)(*[q.data_ptr() for q in q1])
+            t2 = (ctypes.c_void_p * G)(*[q.data_ptr() for q in q2]) if q2 is not None else None
+            self._call("cwf_token_scores2_g", feats.data_ptr(), ctypes.addressof(t1), ctypes.addressof(t2) if t2 is not None else 0, G, b // G,
+                       s1.data_ptr(), _p(s2), b, t, e, self._stream())
+            return s1, s2
         self._call("cwf_token_scores2", feats.data_ptr(), q1.data_ptr(), 0 if q1.shape[0] == 1 else e, _p(q2),
                    0 if (q2 is None or q2.shape[0] == 1) else e, s1.data_ptr(), _p(s2), b, t, e, self._stream())
         return s1, s2
@@ -658,8 +742,12 @@ class HipBackend:
         b = jobs[0][0].shape[0]
         for i, (feats, index, head, out, off) in enumerate(jobs):
             assert out.stride(2) == 1 and out.stride(1) == e and feats.is_contiguous()
-            arr[i] = _lib.GatherJob(feats.data_ptr(), index.data_ptr(), head.data_ptr(), out.data_ptr(), 0 if head.shape[0] == 1 else e,
-                                    out.stride(0), feats.shape[1], off)
+            if isinstance(head, (list, tuple)):              # one shared head per group of b // len(head) samples
+                hg = (ctypes.c_void_p * 4)(*([h.data_ptr() for h in head] + [0] * (4 - len(head))))
+                arr[i] = _lib.GatherJob(feats.data_ptr(), index.data_ptr(), 0, out.data_ptr(), 0, out.stride(0), feats.shape[1], off, hg, b // len(head))
+            else:
+                arr[i] = _lib.GatherJob(feats.data_ptr(), index.data_ptr(), head.data_ptr(), out.data_ptr(), 0 if head.shape[0] == 1 else e,
+                                        out.stride(0), feats.shape[1], off, (ctypes.c_void_p * 4)(), 0)
         self._call("cwf_gather_multi", ctypes.addressof(arr), len(jobs), b, k, e, float(pe_odd), self.rng(jobs[0][0].device).data_ptr(), float(p), self._stream())
 
     def scatter_inv(self, feats, inv, rows, gate, want_gated=True, want_scat=False):
@@ -694,6 +782,12 @@ class HipBackend:
         b, e = a1.shape
         bs = a1.stride(0)
         assert c1.stride(0) == bs and a2.stride(0) == bs and c2.stride(0) == bs
+        if isinstance(out1, (list, tuple)):                  # G groups of b // G samples, one output pair per group
+            G = len(out1)
+            t1 = (ctypes.c_void_p * G)(*[t.data_ptr() for t in out1]); t2 = (ctypes.c_void_p * G)(*[t.data_ptr() for t in out2])
+            self._call("cwf_head_grad_g", a1.data_ptr(), c1.data_ptr(), a2.data_ptr(), c2.data_ptr(), bs, ctypes.addressof(t1), ctypes.addressof(t2),
+                       G, b // G, e, self._stream())
+            return out1, out2
         o1 = out1 if out1 is not None else torch.empty((1, 1, e), dtype=_f32, device=a1.device)
         o2 = out2 if out2 is not None else torch.empty((1, 1, e), dtype=_f32, device=a1.device)
         self._call("cwf_head_grad", a1.data_ptr(), c1.data_ptr(), a2.data_ptr(), c2.data_ptr(), bs, o1.data_ptr(), o2.data_ptr(), b, e, self._stream())

@@ -72,7 +72,14 @@ class ClsWiseFormer(nn.Module):
         self.conv_64_to_32 = HipConv(32, 32, stride=2)
 
         self._packer = CF.WeightPacker()
-        collect_convs(self, self._packer)
+        sem = [getattr(self, "conv_semantic_%d" % k) for k in (1, 2, 4)]
+        mid = [getattr(self, "conv_mid_fea_%d" % k) for k in (1, 2, 4)]
+        collect_convs(self, self._packer, skip=sem + mid)
+        # the three same-input decoupler convs of each kind run as ONE conv (256 -> 3 x 128, 96 -> 3 x 32); parameters stay separate
+        self._sem_spec = CF.FusedConvSpec(sem[0].spec.op, 256, self.item_feature_n)
+        self._mid_spec = CF.FusedConvSpec(mid[0].spec.op, 96, 32)
+        self._packer.add_fused(self._sem_spec, [m.weight for m in sem], [m.bias for m in sem])
+        self._packer.add_fused(self._mid_spec, [m.weight for m in mid], [m.bias for m in mid])
         # test / analysis hooks (not part of the reference interface)
         self.forced_index = None      # dict name -> int tensor [B,k]: teacher-forced top-k selections
         self.collect_aux = False
@@ -89,8 +96,13 @@ class ClsWiseFormer(nn.Module):
         `phase_callback` is set, so that a phase's slice can be reduced / all-reduced while backward continues."""
         dec = list(self.decoder.parameters())
         enc = list(self.Unet_list.parameters()) + list(self.conv_64_to_32.parameters())
-        skip = {id(p) for p in dec + enc}
-        mid = [p for p in self.parameters() if id(p) not in skip]
+        # the fused decoupler layers reduce into ONE slice each: keep their three weights (and three biases) adjacent
+        fused = []
+        for name in ("conv_semantic_%d", "conv_mid_fea_%d"):
+            mods = [getattr(self, name % k) for k in (1, 2, 4)]
+            fused += [m.weight for m in mods] + [m.bias for m in mods]
+        skip = {id(p) for p in dec + enc + fused}
+        mid = fused + [p for p in self.parameters() if id(p) not in skip]
         return [dec, mid, enc]
 
     def _cut(self, t, k, need=1):
@@ -108,39 +120,17 @@ class ClsWiseFormer(nn.Module):
         t.register_hook(hook)
 
     # ------------------------------------------------------------------------------------------------
-    def _coupler_cfg(self, tr, names):
+    def _coupler_cfg(self, tr, names, groups=1):
         """Dropout rates are read from the module tree at call time (tests zero them; the reference's values are 0.1)."""
         pre = tr.cross_attention_list[0].fn
         ff = tr.cross_ffn_list[0].fn.fn
         return CP.CouplerConfig(self.num_heads, self.top_num, self.training, self.dropout_rate, pre.fn.dropout_rate, pre.dropout_rate,
-                                ff.dropout_rate, forced=self.forced_index, names=names)
+                                ff.dropout_rate, forced=self.forced_index, names=names, groups=groups)
 
-    def _region(self, r, k, x23, x4):
-        """Everything that belongs to ONE sub-region (label 1 / 2 / 4): decoupler convs, mid heads, token selection,
-        intra-region coupler, scatter + gate, supervision heads.  The three regions are independent until the fusion."""
-        f, s = getattr(self, "conv_mid_fea_%d" % k)(x23, want_stats=True)           # edge decoupler (:284-296)
-        ef = CF.norm_act_add(f, s, 0.01)
-        f, s = getattr(self, "conv_semantic_%d" % k)(x4, want_stats=True)            # Anatomy-induced Region Decoupler (:314-324)
-        sf = CF.norm_act_add(f, s, 0.01)
-        mid_sup = self.mid_supervise_label.head(k, sf)                               # :332
-        mid_edge = self.mid_edge_supervise_label.head(k, ef)                         # :333
-        sem_size, edge_size = tuple(sf.shape[1:4]), tuple(ef.shape[1:4])
-        E = CF.window_to_tokens(ef, self.edge_patch_size)        # [B,Ne,512]  :341
-        S = CF.window_to_tokens(sf, self.patch_size)             # [B,Ns,512]  :342
-        # selection (:345-376) -> Edge-supported Intra-region Coupler (:379) -> scatter + gate (:463-485): one fused Function
-        names = (r + "_edge", r + "_sem_supp", r + "_sem", r + "_edge_supp")
-        tr = getattr(self, "transformer_" + r)
-        out = CP.RegionCouplerFn.apply(self._coupler_cfg(tr, names), E, S, getattr(self, "e_token_" + r), getattr(self, "s_token_" + r),
-                                       *CP.transformer_params(tr))
-        gated_e, gated_s, scat_s, sem_tok = out[:4]
-        if self.collect_aux:
-            for nm, idx in zip(names, out[4:]):
-                self.aux[nm] = idx
-        sup_edge = CF.tokens_to_window(gated_e, edge_size, self.edge_feature_n, self.edge_patch_size)
-        sup_sem = CF.tokens_to_window(gated_s, sem_size, self.item_feature_n, self.patch_size)
-        sup = self.supervise_label.head(k, sup_sem)                                  # :545
-        edge = self.edge_supervise_label.head(k, sup_edge)                           # :546
-        return dict(mid_sup=mid_sup, mid_edge=mid_edge, sup=sup, edge=edge, sem_token=sem_tok, sem_after=scat_s, sem_size=sem_size)
+    def _heads3(self, heads, feats_all):
+        """the three sub-regions' supervision heads on the channel groups of one tensor (zero-copy slices)"""
+        parts = CP.split_channels3(feats_all)
+        return {r: heads.head(k, p) for r, k, p in zip(REGIONS, (1, 2, 4), parts)}
 
     def encode(self, x, missing_modal=None):
         x1, x2, x3, x4 = self.Unet_list(x)
@@ -148,43 +138,41 @@ class ClsWiseFormer(nn.Module):
         x23 = CF.cat_channels(x2d, x3)
         self._cut(x23, 1, need=2)
         self._cut(x4, 1, need=2)
-
-        # The three sub-region pipelines are made of small, latency-bound kernels (16^3 / 32^3 grids, 129-token GEMMs):
-        # each runs on its own HIP stream so they overlap (under hipGraph capture they become parallel branches).
-        outs = [None, None, None]
-        use_streams = self.parallel_regions and x.is_cuda
-        if use_streams:
-            main = torch.cuda.current_stream()
-            if self._streams is None:
-                self._streams = [torch.cuda.Stream(device=x.device) for _ in REGIONS]
-            for t in (x23, x4):
-                for st in self._streams:
-                    t.record_stream(st)
-            for i, (r, k) in enumerate(zip(REGIONS, (1, 2, 4))):
-                st = self._streams[i]
-                st.wait_stream(main)
-                with torch.cuda.stream(st):
-                    outs[i] = self._region(r, k, x23, x4)
-            for i, st in enumerate(self._streams):
-                main.wait_stream(st)
-                for v in outs[i].values():
-                    if torch.is_tensor(v):
-                        v.record_stream(main)
-        else:
-            for i, (r, k) in enumerate(zip(REGIONS, (1, 2, 4))):
-                outs[i] = self._region(r, k, x23, x4)
-
-        pick = lambda key: {r: o[key] for r, o in zip(REGIONS, outs)}
-        sup, edge, mid_sup, mid_edge = pick("sup"), pick("edge"), pick("mid_sup"), pick("mid_edge")
-        sem_tokens = [o["sem_token"] for o in outs]
-        sem_after = [o["sem_after"] for o in outs]
-        sem_size = outs[0]["sem_size"]
+        G = len(REGIONS)
+        # edge decoupler (:284-296) and Anatomy-induced Region Decoupler (:314-324): the three same-input convs of each as one launch
+        f, s = CF.fused_conv3(x23, [getattr(self, "conv_mid_fea_%d" % k) for k in (1, 2, 4)], self._mid_spec)
+        ef = CF.norm_act_add(f, s, 0.01)                           # [B,32^3,3*32]
+        f, s = CF.fused_conv3(x4, [getattr(self, "conv_semantic_%d" % k) for k in (1, 2, 4)], self._sem_spec)
+        sf = CF.norm_act_add(f, s, 0.01)                           # [B,16^3,3*128]
+        mid_sup = self._heads3(self.mid_supervise_label, sf)       # :332
+        mid_edge = self._heads3(self.mid_edge_supervise_label, ef)  # :333
+        sem_size, edge_size = tuple(sf.shape[1:4]), tuple(ef.shape[1:4])
+        E = CP.window_to_tokens_g(ef, G, self.edge_patch_size)     # [3,B,Ne,512]  :341
+        S = CP.window_to_tokens_g(sf, G, self.patch_size)          # [3,B,Ns,512]  :342
+        # selection (:345-376) -> Edge-supported Intra-region Coupler (:379) -> scatter + gate (:463-485), all three regions per launch
+        names = [(r + "_edge", r + "_sem_supp", r + "_sem", r + "_edge_supp") for r in REGIONS]
+        trs = [getattr(self, "transformer_" + r) for r in REGIONS]
+        cfg = self._coupler_cfg(trs[0], names, groups=G)
+        flat = [getattr(self, "e_token_" + r) for r in REGIONS] + [getattr(self, "s_token_" + r) for r in REGIONS]
+        for tr in trs:
+            flat += list(CP.transformer_params(tr))
+        out = CP.RegionCouplerFn.apply(cfg, E, S, *flat)
+        gated_e, gated_s, scat_s, sem_tok = out[:4]
+        if self.collect_aux:
+            b = x.shape[0]
+            for j, idx in enumerate(out[4:]):
+                for g in range(G):
+                    self.aux[names[g][j]] = idx[g * b:(g + 1) * b]
+        sup_edge = CP.tokens_to_window_g(gated_e, edge_size, self.edge_feature_n, self.edge_patch_size)
+        sup_sem = CP.tokens_to_window_g(gated_s, sem_size, self.item_feature_n, self.patch_size)
+        sup = self._heads3(self.supervise_label, sup_sem)          # :545
+        edge = self._heads3(self.edge_supervise_label, sup_edge)   # :546
 
         # Mutual Cross-region Coupler (:549-579): post-scatter UN-gated semantic tokens are fused
-        f_tok = CP.add3(sem_tokens[0], sem_tokens[1], sem_tokens[2])
-        f_feat = CP.add3(sem_after[0], sem_after[1], sem_after[2])
+        f_tok = CP.add3(sem_tok[0], sem_tok[1], sem_tok[2])
+        f_feat = CP.add3(scat_s[0], scat_s[1], scat_s[2])
         tr = self.fusion_transformer_1_2_4
-        fused, f_idx = CP.FusionCouplerFn.apply(self._coupler_cfg(tr, ("fusion",)), f_feat, f_tok, *CP.transformer_params(tr))
+        fused, f_idx = CP.FusionCouplerFn.apply(self._coupler_cfg(tr, [("fusion",)]), f_feat, f_tok, *CP.transformer_params(tr))
         if self.collect_aux:
             self.aux["fusion"] = f_idx
         xb = CF.tokens_to_window(fused, sem_size, self.item_feature_n, self.patch_size)

@@ -30,7 +30,9 @@ class HipConv(nn.Module):
         return CF.conv(x, self.weight, self.bias, self.spec, in_norm, slope, residual, out_scale, want_stats, carry)
 
 
-def collect_convs(module, packer):
+def collect_convs(module, packer, skip=()):
+    """register every conv weight for the once-per-step packing launch (`skip`: layers that run as part of a fused layer)"""
+    skip = {id(m) for m in skip}
     for m in module.modules():
-        if isinstance(m, HipConv):
+        if isinstance(m, HipConv) and id(m) not in skip:
             packer.add(m.spec, m.weight)

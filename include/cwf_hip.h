@@ -179,6 +179,9 @@ struct cwf_gemm_args {
   const uint64_t* rng;
   uint64_t a_drop_off, a_drop_n; float a_drop_p, a_drop_p2;
   uint64_t c_drop_off, c_drop_n; float c_drop_p, c_drop_p2;
+  /* grouped form (the three sub-regions' couplers in one launch, z = group): per-z pointers override B / bias / C / rowsum
+   * when the first entry is non-NULL (separate weight tensors per group; A, residual, C2 stay strided) */
+  const float* B_tab[4]; const float* bias_tab[4]; float* C_tab[4]; float* rowsum_tab[4];
 };
 int cwf_gemm_ex(const struct cwf_gemm_args* args /* host */, void* stream);
 
@@ -202,6 +205,15 @@ int cwf_attn_bwd(const float* qkv, int64_t ld, const float* d_o, int64_t ldo, fl
  *   dg*, db* (+)= per-column sums (accumulate_params: the weight-sharing sum over the uses of one block)                  */
 int cwf_ln_pair_fwd(const float* x, const float* x2, int perm_T, const float* g1, const float* b1, const float* g2, const float* b2,
                     float* ya, float* yb, float* stats, int rows, int E, float eps, void* stream);
+/* grouped forms: rows = groups * rows_per_group, group g uses the g-th LayerNorm parameter set (host arrays of `groups` <= 4 device
+ * pointers; the parameter-gradient outputs likewise) -- the three sub-regions' couplers normalised in one launch */
+struct cwf_ln_group_params { const float* g1[4]; const float* b1[4]; const float* g2[4]; const float* b2[4];
+                             float* dg1[4]; float* db1[4]; float* dg2[4]; float* db2[4]; };
+int cwf_ln_pair_fwd_g(const float* x, const float* x2, int perm_T, const struct cwf_ln_group_params* h_params, int groups,
+                      float* ya, float* yb, float* stats, int rows, int E, float eps, void* stream);
+int cwf_ln_pair_bwd_g(const float* dy, const float* da, const float* db, const float* x, const float* x2, int perm_T,
+                      const struct cwf_ln_group_params* h_params, int groups, const float* stats, float* dx, float* dx2,
+                      int rows, int E, int accumulate_params, void* stream);
 int cwf_ln_pair_bwd(const float* dy, const float* da, const float* db, const float* x, const float* x2, int perm_T,
                     const float* g1, const float* g2, const float* stats, float* dx, float* dx2,
                     float* dg1, float* db1, float* dg2, float* db2, int rows, int E, int accumulate_params, void* stream);
@@ -258,6 +270,9 @@ int cwf_scatter_rows_bwd(const float* dout, const int32_t* index, const float* s
 /* s1[b][t] = feats[b][t].q1[b or 0], s2 likewise for q2 (nullable): both class tokens of a region against one token matrix */
 int cwf_token_scores2(const float* feats, const float* q1, int64_t q1_bstride, const float* q2, int64_t q2_bstride,
                       float* s1, float* s2, int B, int T, int E, void* stream);
+/* grouped: sample b belongs to group b / group_B and is scored against that group's shared queries (host arrays of pointers) */
+int cwf_token_scores2_g(const float* feats, const float* const* h_q1, const float* const* h_q2, int groups, int group_B,
+                        float* s1, float* s2, int B, int T, int E, void* stream);
 /* top-k of one or two score vectors [B][T] (same T, k) in one launch; inv*[b][t] = rank of token t if selected else -1 (nullable);
  * NaN scores order as the largest value (torch.topk) */
 int cwf_topk_inv(const float* score0, int32_t* index0, int32_t* inv0, const float* score1, int32_t* index1, int32_t* inv1,
@@ -267,7 +282,8 @@ int cwf_index_inv(const int32_t* index, int32_t* inv, int B, int T, int k, void*
 /* up to four gathers in one launch: out[b][0] = head[b or 0] ; out[b][1+j] = (feats[b][index[b][j]] + pe) * keep
  * (the four 129-token sequences of a region written straight into the paired [B][2][129][E] operands; :345-376) */
 struct cwf_gather_job { const float* feats; const int32_t* index; const float* head; float* out;
-                        int64_t head_bstride, out_bstride; int T; uint64_t drop_off; };
+                        int64_t head_bstride, out_bstride; int T; uint64_t drop_off;
+                        const float* head_g[4]; int group_B; /* group_B > 0: sample b takes head_g[b / group_B] (shared per group) */ };
 int cwf_gather_multi(const struct cwf_gather_job* jobs /* host */, int njobs, int B, int k, int E, float pe_odd,
                      const uint64_t* rng, float p, void* stream);
 /* scat = feats with the selected rows replaced (via inv) ; gated = scat * gate ; either output may be NULL      (:463-485) */
@@ -288,6 +304,17 @@ int cwf_token_grad(const float* dgated, const float* dscat, const float* gate, i
 /* class-token gradients: out1 = sum_b (a1[b] + c1[b]), out2 = sum_b (a2[b] + c2[b]) over rows of stride bstride */
 int cwf_head_grad(const float* a1, const float* c1, const float* a2, const float* c2, int64_t bstride,
                   float* out1, float* out2, int B, int E, void* stream);
+/* grouped: group g sums its samples [g*group_B, (g+1)*group_B) into h_out1[g] / h_out2[g] */
+int cwf_head_grad_g(const float* a1, const float* c1, const float* a2, const float* c2, int64_t bstride,
+                    float* const* h_out1, float* const* h_out2, int groups, int group_B, int E, void* stream);
+/* window <-> token reshapes of `groups` channel groups of one NDHWC tensor in one launch:
+ *   tok[g][b][t][f] = x[b][voxel][g*C + c]   and the inverse (x_ldc >= groups*C) */
+int cwf_window_to_tokens_g(const float* x, int x_ldc, float* tok, int groups, int B, int D, int H, int W, int C,
+                           int p0, int p1, int p2, void* stream);
+int cwf_tokens_to_window_g(const float* tok, float* x, int x_ldc, int groups, int B, int D, int H, int W, int C,
+                           int p0, int p1, int p2, void* stream);
+/* y[v][g*C + c] = xs[g][v][c] (NULL source: zeros), g < 3: the adjoint of slicing one tensor into three channel groups */
+int cwf_cat3_channels(const float* x0, const float* x1, const float* x2, float* y, int64_t nvox, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K8/K10  heads: trilinear upsample (align_corners=False) + channel softmax; 4-class channel softmax

@@ -249,6 +249,16 @@ class EmulBackend:
         t = tok.reshape(b, d // p0, h // p1, w // p2, channels, p0, p1, p2).permute(0, 4, 1, 5, 2, 6, 3, 7)
         return _ndhwc(t.reshape(b, channels, d, h, w))
 
+    def window_to_tokens_g(self, x, groups, patch):
+        c = x.shape[-1] // groups
+        return torch.stack([self.window_to_tokens(x[..., g * c:(g + 1) * c], patch) for g in range(groups)], 0)
+
+    def tokens_to_window_g(self, tok, size, channels, patch):
+        return torch.cat([self.tokens_to_window(tok[g], size, channels, patch) for g in range(tok.shape[0])], -1)
+
+    def cat3_channels(self, parts, shape, device):
+        return torch.cat([torch.zeros(shape) if t is None else t for t in parts], -1)
+
     def token_scores(self, feats, query):
         return torch.einsum("bte,be->bt", feats, query.expand(feats.shape[0], -1, -1)[:, 0])
 
@@ -291,12 +301,24 @@ class EmulBackend:
         return self.keep(off, m * n, p, p2).reshape(m, n)
 
     def linear_fwd(self, x, w, bias, out, x2=None, split_n=0, act=0, pre=None, drop=None, residual=None):
-        """cwf_gemm_ex as nn.Linear (+ GELU, + Dropout, + residual): SelfAttention.py:80-102, ResidualNorm.py:35-47."""
-        v = x @ w.t()
-        if x2 is not None:
-            v[:, split_n:] = x2 @ w[split_n:].t()
-        if bias is not None:
-            v = v + bias
+        """cwf_gemm_ex as nn.Linear (+ GELU, + Dropout, + residual): SelfAttention.py:80-102, ResidualNorm.py:35-47.
+        w / bias may be lists of G weight sets: the rows are then G stacked problems."""
+        if isinstance(w, (list, tuple)):
+            G, mg = len(w), x.shape[0] // len(w)
+            parts = []
+            for g in range(G):
+                r = slice(g * mg, (g + 1) * mg)
+                vg = x[r] @ w[g].t()
+                if x2 is not None:
+                    vg[:, split_n:] = x2[r] @ w[g][split_n:].t()
+                parts.append(vg + bias[g] if bias is not None else vg)
+            v = torch.cat(parts, 0)
+        else:
+            v = x @ w.t()
+            if x2 is not None:
+                v[:, split_n:] = x2 @ w[split_n:].t()
+            if bias is not None:
+                v = v + bias
         if pre is not None:
             pre.copy_(v)
         if act == 1:
@@ -312,7 +334,11 @@ class EmulBackend:
     def linear_dgrad(self, dy, w, drop=None, out=None):
         mk = self._mask2d(drop, *dy.shape)
         d = dy * mk if mk is not None else dy
-        dx = d @ w
+        if isinstance(w, (list, tuple)):
+            mg = dy.shape[0] // len(w)
+            dx = torch.cat([d[g * mg:(g + 1) * mg] @ w[g] for g in range(len(w))], 0)
+        else:
+            dx = d @ w
         if out is not None:
             out.copy_(dx)
             return out
@@ -321,6 +347,12 @@ class EmulBackend:
     def linear_wgrad(self, dy, x, dw, dbias=None, x2=None, split_m=0, accumulate=False, drop=None):
         mk = self._mask2d(drop, *dy.shape)
         d = dy * mk if mk is not None else dy
+        if isinstance(dw, (list, tuple)):
+            mg = dy.shape[0] // len(dw)
+            for gi in range(len(dw)):
+                r = slice(gi * mg, (gi + 1) * mg)
+                self.linear_wgrad(d[r], x[r], dw[gi], dbias[gi] if dbias is not None else None, x2[r] if x2 is not None else None, split_m, accumulate)
+            return
         g = d.t() @ x
         if x2 is not None:
             g[split_m:] = d[:, split_m:].t() @ x2
@@ -336,6 +368,12 @@ class EmulBackend:
     def ln_pair_fwd(self, x, x2, perm_T, g1, b1, g2, b2, eps=1e-5):
         """nn.LayerNorm(x), nn.LayerNorm(x2[perm]) (PreNormDrop, ResidualNorm.py:23-32) + (mean, rstd) per row."""
         rows = x.shape[0]
+        if isinstance(g1, (list, tuple)):
+            G, rg = len(g1), rows // len(g1)
+            outs = [self.ln_pair_fwd(x[i * rg:(i + 1) * rg], None if x2 is None else x2[i * rg:(i + 1) * rg], perm_T, g1[i], b1[i],
+                                     None if g2 is None else g2[i], None if b2 is None else b2[i], eps) for i in range(G)]
+            return (torch.cat([o[0] for o in outs], 0), None if x2 is None else torch.cat([o[1] for o in outs], 0),
+                    torch.cat([o[2] for o in outs], 1))
 
         def one(v, g, b):
             mean = v.mean(-1)
@@ -349,6 +387,13 @@ class EmulBackend:
 
     def ln_pair_bwd(self, dy, da, db, x, x2, perm_T, g1, g2, stats, dg1, db1, dg2, db2, accumulate, want_dx2):
         rows, e = x.shape
+        if isinstance(g1, (list, tuple)):
+            G, rg = len(g1), rows // len(g1)
+            sl = lambda t, i: None if t is None else t[i * rg:(i + 1) * rg]
+            pick = lambda t, i: None if t is None else t[i]
+            outs = [self.ln_pair_bwd(sl(dy, i), sl(da, i), sl(db, i), sl(x, i), sl(x2, i), perm_T, g1[i], pick(g2, i), stats[:, i * rg:(i + 1) * rg],
+                                     dg1[i], db1[i], pick(dg2, i), pick(db2, i), accumulate, want_dx2) for i in range(G)]
+            return torch.cat([o[0] for o in outs], 0), (torch.cat([o[1] for o in outs], 0) if want_dx2 else None)
 
         def lnb(d, v, g, st):
             xh = (v - st[:, 0:1]) * st[:, 1:2]
@@ -396,6 +441,10 @@ class EmulBackend:
 
     # ------------------------------------------------------------------ K4/K5 round-2 forms
     def token_scores2(self, feats, q1, q2=None):
+        if isinstance(q1, (list, tuple)):                   # G shared queries, sample b in group b // (B / G)
+            bg = feats.shape[0] // len(q1)
+            q1 = torch.cat([q.expand(bg, -1, -1) for q in q1], 0)
+            q2 = torch.cat([q.expand(bg, -1, -1) for q in q2], 0) if q2 is not None else None
         return self.token_scores(feats, q1), (self.token_scores(feats, q2) if q2 is not None else None)
 
     def _inv(self, index, t):
@@ -422,6 +471,8 @@ class EmulBackend:
     def gather_multi(self, jobs, k, e, p=0.0, pe_odd=1.0):
         for feats, index, head, out, off in jobs:
             b = feats.shape[0]
+            if isinstance(head, (list, tuple)):
+                head = torch.cat([h.expand(b // len(head), -1, -1) for h in head], 0)
             keep = self.keep(off, b * k * e, p).reshape(b, k, e) if p > 0.0 else None
             out.copy_(self.gather_tokens(feats, index, head, keep, pe_odd))
 
@@ -467,6 +518,12 @@ class EmulBackend:
         return out
 
     def head_grad(self, a1, c1, a2, c2, out1=None, out2=None):
+        if isinstance(out1, (list, tuple)):
+            bg = a1.shape[0] // len(out1)
+            for g in range(len(out1)):
+                r = slice(g * bg, (g + 1) * bg)
+                out1[g].copy_((a1[r] + c1[r]).sum(0).reshape(out1[g].shape)); out2[g].copy_((a2[r] + c2[r]).sum(0).reshape(out2[g].shape))
+            return out1, out2
         o1, o2 = (a1 + c1).sum(0).reshape(1, 1, -1), (a2 + c2).sum(0).reshape(1, 1, -1)
         if out1 is not None:
             out1.copy_(o1); o1 = out1
@@ -553,10 +610,12 @@ class EmulBackend:
     # ------------------------------------------------------------------ K11 / misc
     def wgrad_to(self, key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec=None, allow_async=False):
         """gradient-sink form of wgrad: the result lands in (dw_dst, db_dst) directly (the HIP backend defers the reduction)"""
-        gw, gb = self.wgrad(op, x, in_scale, in_shift, slope, dy, cout, inv_map, db_dst is not None, dw_dst.numel(), w_ref_shape=dw_dst.shape)
-        dw_dst.copy_(gw.view_as(dw_dst))
+        shape = (cout,) + tuple(dw_dst.shape[1:]) if op != CONVT2 else tuple(dw_dst.shape)
+        gw, gb = self.wgrad(op, x, in_scale, in_shift, slope, dy, cout, inv_map, db_dst is not None, 0, w_ref_shape=shape)
+        # a fused layer (three convs on one input) reduces into ADJACENT slices of the flat buffer starting at dw_dst / db_dst
+        torch.as_strided(dw_dst, (gw.numel(),), (1,), dw_dst.storage_offset()).copy_(gw.reshape(-1))
         if db_dst is not None:
-            db_dst.copy_(gb)
+            torch.as_strided(db_dst, (gb.numel(),), (1,), db_dst.storage_offset()).copy_(gb)
 
     def wgrad_flush(self, device=None):
         pass

@@ -232,15 +232,17 @@ def _weights(seed):
 @pytest.mark.parametrize("training", [False, True])
 def test_region_and_fusion_coupler_functions(hip, training):
     """The whole Functions, HIP vs the same host code over the oracle backend: outputs and every gradient (token matrices, class
-    tokens, the 13 shared weights).  Selections are teacher-forced from the oracle run (a near-tie flip would change everything);
-    training=True switches every dropout site on (p = 0.1) with the generator states synchronised."""
+    tokens, the 13 weights of each of the THREE sub-regions' weight sets -- one grouped launch per stage covers all three).
+    Selections are teacher-forced from the oracle run (a near-tie flip would change everything); training=True switches every
+    dropout site on (p = 0.1) with the generator states synchronised."""
     from cwf import coupler as CP, kernels
-    b, te, ts, e = 2, 2048, 1024, 512
-    Em, Sm = rnd(b, te, e, seed=1), rnd(b, ts, e, seed=2)
-    etok, stok = rnd(1, 1, e, seed=3) * 0.05, rnd(1, 1, e, seed=4) * 0.05
-    W = _weights(100)
-    names = ("r_edge", "r_sem_supp", "r_sem", "r_edge_supp")
-    douts = [rnd(b, te, e, seed=5), rnd(b, ts, e, seed=6), rnd(b, ts, e, seed=7), rnd(b, 1, e, seed=8)]
+    G, b, te, ts, e = 3, 2, 2048, 1024, 512
+    Em, Sm = rnd(G, b, te, e, seed=1), rnd(G, b, ts, e, seed=2)
+    etoks = [rnd(1, 1, e, seed=3 + g) * 0.05 for g in range(G)]
+    stoks = [rnd(1, 1, e, seed=13 + g) * 0.05 for g in range(G)]
+    W = [w for g in range(G) for w in _weights(100 + 50 * g)]
+    names = [tuple("r%d_%s" % (g, n) for n in ("edge", "sem_supp", "sem", "edge_supp")) for g in range(G)]
+    douts = [rnd(G, b, te, e, seed=5), rnd(G, b, ts, e, seed=6), rnd(G, b, ts, e, seed=7), rnd(G, b, 1, e, seed=8)]
 
     def run(on_hip, forced):
         if on_hip:
@@ -252,22 +254,24 @@ def test_region_and_fusion_coupler_functions(hip, training):
             K = EmulBackend(); K.set_rng(seed, step + (0 if forced is not None else 1)); K._site = 0
             kernels._set_backend_for_testing(K)
             dev = "cpu"
-        leaves = [t.clone().to(dev).requires_grad_(True) for t in [Em, Sm, etok, stok] + W]
-        cfg = CP.CouplerConfig(8, 128, training, 0.1, 0.1, 0.1, 0.1, forced={k: v.to(dev) for k, v in (forced or {}).items()}, names=names)
+        leaves = [t.clone().to(dev).requires_grad_(True) for t in [Em, Sm] + etoks + stoks + W]
+        cfg = CP.CouplerConfig(8, 128, training, 0.1, 0.1, 0.1, 0.1, forced={k: v.to(dev) for k, v in (forced or {}).items()}, names=names, groups=G)
         out = CP.RegionCouplerFn.apply(cfg, *leaves)
         sum((o * d.to(dev)).sum() for o, d in zip(out[:4], douts)).backward()
         return out, [t.grad for t in leaves]
 
     try:
         oe, ge = run(False, None)                       # oracle first: its selections are then forced on both sides
-        forced = dict(zip(names, [i.long() for i in oe[4:]]))
+        forced = {names[g][j]: oe[4 + j][g * b:(g + 1) * b].long() for g in range(G) for j in range(4)}
         oh, gh = run(True, forced)
         oe, ge = run(False, forced)
     finally:
         kernels._set_backend_for_testing(hip)
     for a, r, nm in zip(oh[:4], oe[:4], ("gated_e", "gated_s", "scat_s", "sem_tok")):
         close(a, r, rtol=1e-4, what=nm)
-    gn = ["dE", "dS", "d e_tok", "d s_tok", "ln1.w", "ln1.b", "ln2.w", "ln2.b", "out.w", "out.b", "qkv.w", "ffn.ln.w", "ffn.ln.b", "w1", "b1", "w2", "b2"]
+    wn = ["ln1.w", "ln1.b", "ln2.w", "ln2.b", "out.w", "out.b", "qkv.w", "ffn.ln.w", "ffn.ln.b", "w1", "b1", "w2", "b2"]
+    gn = ["dE", "dS"] + ["d e_tok%d" % g for g in range(G)] + ["d s_tok%d" % g for g in range(G)] + ["set%d %s" % (g, n) for g in range(G) for n in wn]
+    assert len(gn) == len(gh)
     for a, r, nm in zip(gh, ge, gn):
         close(a, r, rtol=5e-4, what=nm)
 
@@ -285,8 +289,8 @@ def test_region_and_fusion_coupler_functions(hip, training):
             K = EmulBackend(); K.set_rng(seed, step + (0 if forced is not None else 1)); K._site = 0
             kernels._set_backend_for_testing(K)
             dev = "cpu"
-        leaves = [t.clone().to(dev).requires_grad_(True) for t in [feats, tok] + W]
-        cfg = CP.CouplerConfig(8, 128, training, 0.1, 0.1, 0.1, 0.1, forced={k: v.to(dev) for k, v in (forced or {}).items()}, names=("fusion",))
+        leaves = [t.clone().to(dev).requires_grad_(True) for t in [feats, tok] + W[:13]]
+        cfg = CP.CouplerConfig(8, 128, training, 0.1, 0.1, 0.1, 0.1, forced={k: v.to(dev) for k, v in (forced or {}).items()}, names=[("fusion",)])
         fused, idx = CP.FusionCouplerFn.apply(cfg, *leaves)
         (fused * dfused.to(dev)).sum().backward()
         return fused, idx, [t.grad for t in leaves]
@@ -298,5 +302,55 @@ def test_region_and_fusion_coupler_functions(hip, training):
     finally:
         kernels._set_backend_for_testing(hip)
     close(fh, fe, rtol=1e-4, what="fused")
-    for a, r, nm in zip(gh, ge, ["dfeats", "dtok"] + gn[4:]):
+    for a, r, nm in zip(gh, ge, ["dfeats", "dtok"] + wn):
         close(a, r, rtol=5e-4, what="fusion " + nm)
+
+
+def test_grouped_window_kernels_and_fused_decoupler_conv(hip):
+    """(a) window <-> token reshapes of three channel groups in one launch == the per-group kernels; cat3 = adjoint of the channel
+    split.  (b) FusedConvSpec: conv_semantic_{1,2,4} / conv_mid_fea_{1,2,4} (three convs on one input) as ONE conv with three
+    separate parameter tensors -- forward, data gradient and weight / bias gradients against the three separate convs."""
+    from cwf import functional as CF, kernels, packing as pk
+    E = EmulBackend()
+    x = rnd(2, 8, 8, 8, 3 * 32, seed=1)
+    tok = hip.window_to_tokens_g(x.to(DEV), 3, (4, 2, 2))
+    assert torch.equal(tok.cpu(), E.window_to_tokens_g(x, 3, (4, 2, 2)))
+    assert torch.equal(hip.tokens_to_window_g(tok, (8, 8, 8), 32, (4, 2, 2)).cpu(), x)
+    parts = [rnd(2, 4, 4, 4, 16, seed=s_) for s_ in (2, 3)]
+    y = hip.cat3_channels([parts[0].to(DEV), None, parts[1].to(DEV)], (2, 4, 4, 4, 16), DEV).cpu()
+    assert torch.equal(y[..., :16], parts[0]) and float(y[..., 16:32].abs().max()) == 0 and torch.equal(y[..., 32:], parts[1])
+    for prec, tol in (("fp32", 2e-5), ("bf16x3", 2e-4)):
+        kernels.set_precision(prec)
+        try:
+            for cin, cout, size in ((96, 32, (8, 8, 8)), (256, 128, (4, 6, 4))):
+                convs = [torch.nn.Conv3d(cin, cout, 3, padding=1).to(DEV) for _ in range(3)]
+                spec = CF.FusedConvSpec(pk.CONV3_S1, cin, cout)
+                packer = CF.WeightPacker()
+                single = []
+                from models.clswiseformer.layers import HipConv
+                for c in convs:
+                    h = HipConv(cin, cout).to(DEV)
+                    h.weight.data.copy_(c.weight.data); h.bias.data.copy_(c.bias.data)
+                    single.append(h)
+                    packer.add(h.spec, h.weight)
+                packer.add_fused(spec, [h.weight for h in single], [h.bias for h in single])
+                packer.refresh()
+                xin = rnd(2, *size, cin, seed=9).to(DEV).requires_grad_(True)
+                y, (sc, sh) = CF.fused_conv3(xin, single, spec)
+                dy = rnd(*y.shape, seed=10).to(DEV)
+                y.backward(dy)
+                gx = xin.grad.clone(); gw = [h.weight.grad.clone() for h in single]; gb = [h.bias.grad.clone() for h in single]
+                xin.grad = None
+                for h in single:
+                    h.weight.grad = None; h.bias.grad = None
+                ys = [h(xin, want_stats=True) for h in single]
+                yref = torch.cat([t[0] for t in ys], -1)
+                close(y, yref, rtol=tol, what="fused forward")
+                close(sc, torch.cat([t[1][0] for t in ys], -1), rtol=10 * tol, what="fused stats")
+                yref.backward(dy)
+                close(gx, xin.grad, rtol=tol, what="fused dgrad")
+                for g in range(3):
+                    close(gw[g], single[g].weight.grad, rtol=5 * tol, what="fused wgrad %d" % g)
+                    close(gb[g], single[g].bias.grad, rtol=5 * tol, what="fused bias grad %d" % g)
+        finally:
+            kernels.set_precision("fp32")
