@@ -351,7 +351,9 @@ def test_gradient_sink_equals_plain_autograd(hip):
             loss.backward()
             plain.append({n: p.grad.clone() for n, p in m.named_parameters()})
         noise = max(float((plain[0][n] - plain[1][n]).norm() / (plain[0][n].norm() + 1e-30)) for n in plain[0] if float(plain[0][n].norm()) > 1e-7)
-        m = _no_dropout_model(forced)
+        gold = np.load(os.path.join(GOLDEN, "model_64.npz"))
+        true_zero = {n for n, v in zip(gold["grad_names"], gold["grad_l2_f64"]) if v <= 1e-7}   # conv biases in front of an InstanceNorm:
+        m = _no_dropout_model(forced)                      # their computed "gradient" is cancellation noise, summation order matters
         tr = Trainer(m)
         for rep in range(2):                               # twice: the second step reuses the cached descriptor tables / slab buffers
             tr._fwd_bwd(x, target, edge)
@@ -363,7 +365,7 @@ def test_gradient_sink_equals_plain_autograd(hip):
                 g = tr.opt.flat_grad[off:off + p.numel()].view_as(p)
                 off += p.numel()
                 ref = plain[0][names[id(p)]]
-                if float(ref.norm()) > 1e-7:
+                if float(ref.norm()) > 1e-7 and names[id(p)] not in true_zero:
                     d = float((g - ref).norm() / ref.norm())
                     assert d < max(5e-5, 10 * noise), (names[id(p)], d, noise, rep)
         assert [hi - lo for lo, hi in tr.opt.sink.chunks] == [sum(p.numel() for p in ph) for ph in m.grad_phases()]
