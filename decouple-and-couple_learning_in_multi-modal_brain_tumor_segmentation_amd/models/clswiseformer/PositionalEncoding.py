@@ -20,3 +20,14 @@ class ExtendFixedPositionalEncoding(nn.Module):
 
     #: value added to odd channels of every token (cos(0)); even channels get sin(0) = 0
     PE_ODD = 1.0
+
+
+class LearnedPositionalEncoding(nn.Module):
+    """Parameter holder with the reference's shape (PositionalEncoding.py:46-55).  The reference constructs it as
+    ``LearnedPositionalEncoding(129, 512)`` (cls_wise_former.py:87-90), i.e. a [1, 512, 129] parameter that cannot be added to the
+    [B, 128, 512] token rows: with ``_pe_type="learned"`` (the factory's own default) the reference model constructs but its forward
+    raises.  This package mirrors that: construction works (same state_dict keys and shapes), forward raises."""
+
+    def __init__(self, embedding_dim, seq_length):
+        super().__init__()
+        self.position_embeddings = nn.Parameter(torch.zeros(1, seq_length, embedding_dim))

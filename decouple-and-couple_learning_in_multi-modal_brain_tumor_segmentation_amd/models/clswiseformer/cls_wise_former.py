@@ -24,7 +24,7 @@ from cwf.kernels import backend
 from .layers import HipConv, collect_convs
 from .Unet_skipconnection import Unet
 from .transformer import TwoClsWiseTransformerModel, FusionClsWiseTransformerModel
-from .PositionalEncoding import ExtendFixedPositionalEncoding
+from .PositionalEncoding import ExtendFixedPositionalEncoding, LearnedPositionalEncoding
 from .heads import SuperviseLabel, EdgeSuperviseLabel
 
 REGIONS = ("01", "02", "04")
@@ -36,9 +36,9 @@ class ClsWiseFormer(nn.Module):
                  positional_encoding_type="learned", gpu=0):
         super().__init__()
         assert embedding_dim % num_heads == 0 and img_dim % patch_dim == 0
-        if positional_encoding_type != "fixed":
-            raise NotImplementedError("every reference script passes _pe_type='fixed' (train_no_amp.py:130); "
-                                      "the 'learned' variant is dead code there and is not built")
+        if positional_encoding_type not in ("fixed", "learned"):
+            raise ValueError("positional_encoding_type must be 'fixed' or 'learned'")
+        self.positional_encoding_type = positional_encoding_type
         self.embedding_dim, self.num_heads = embedding_dim, num_heads
         self.dropout_rate, self.attn_dropout_rate = dropout_rate, attn_dropout_rate
         self.item_feature_n, self.edge_feature_n, self.top_num = 128, 32, 128
@@ -53,7 +53,9 @@ class ClsWiseFormer(nn.Module):
             nn.init.trunc_normal_(getattr(self, "e_token_" + r), std=0.02)
             nn.init.trunc_normal_(getattr(self, "s_token_" + r), std=0.02)
         for r in REGIONS:
-            setattr(self, "label_%s_position_encoding" % r, ExtendFixedPositionalEncoding(tok_dim, 1024))
+            # "learned" (the factory's default, unused by every reference script): constructs like the reference, cannot run there or here
+            setattr(self, "label_%s_position_encoding" % r, ExtendFixedPositionalEncoding(tok_dim, 1024)
+                    if positional_encoding_type == "fixed" else LearnedPositionalEncoding(129, 512))
         for r in REGIONS:
             setattr(self, "transformer_" + r, TwoClsWiseTransformerModel(1, num_heads, tok_dim, dropout_rate, attn_dropout_rate))
         self.fusion_label_pos = ExtendFixedPositionalEncoding(tok_dim, 1024)
@@ -184,6 +186,10 @@ class ClsWiseFormer(nn.Module):
 
     def forward(self, x, missing_modal=None):
         backend()                                                     # raises if the HIP library / GPU is missing
+        if self.positional_encoding_type != "fixed":
+            raise RuntimeError("_pe_type='learned': the reference builds LearnedPositionalEncoding(129, 512), a [1,512,129] parameter that "
+                               "cannot be added to the [B,128,512] token rows (cls_wise_former.py:87-90,348) -- its forward raises too; "
+                               "every reference script passes _pe_type='fixed' (train_no_amp.py:130)")
         if x.dim() != 5 or x.shape[1] != 4:
             raise ValueError("expected x of shape [B,4,D,H,W], got %s" % (tuple(x.shape),))
         _, _, d, h, w = x.shape

@@ -242,13 +242,26 @@ def adam_fixture():
 
 
 def main():
+    """python oracle/make_golden.py [--only TAG ...]   TAG in {losses, adam, 64, 128, noncubic, config4}"""
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    only = set(sys.argv[sys.argv.index("--only") + 1:]) if "--only" in sys.argv else None
+    want = lambda t: only is None or t in only
     get_model, criterions, tools = import_reference()
-    loss_fixtures(criterions, tools)
-    adam_fixture()
-    whole_model(get_model, criterions, tools, (64, 64, 64), "64")
-    whole_model(get_model, criterions, tools, (128, 128, 128), "128")
+    if want("losses"):
+        loss_fixtures(criterions, tools)
+    if want("adam"):
+        adam_fixture()
+    if want("64"):
+        whole_model(get_model, criterions, tools, (64, 64, 64), "64")
+    if want("128"):
+        whole_model(get_model, criterions, tools, (128, 128, 128), "128")
+    # non-cubic patches (BASELINE configs[4] trains on 160x192x160): the reference with image_size / edge_image_size patched and a
+    # fix_index.txt of >= 4800 keys (SURVEY 8d "Config 5") -- pins the repo's size generalisation (F3) against the reference itself
+    if want("noncubic"):
+        whole_model(get_model, criterions, tools, (64, 96, 80), "noncubic")
+    if want("config4"):
+        whole_model(get_model, criterions, tools, (160, 192, 160), "config4", with_grad=False)
     print("golden fixtures written to", GOLD)
 
 

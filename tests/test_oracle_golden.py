@@ -52,9 +52,13 @@ def test_losses_against_reference_fixture():
         assert np.allclose(outs[r].grad.numpy(), g["edge_grad_" + r], rtol=1e-5, atol=1e-9)
 
 
-def test_forward_64_against_reference_fixture():
-    g = np.load(os.path.join(GOLDEN, "model_64.npz"))
-    x, target, edge = syn.synthetic_batch([0], (64, 64, 64))
+@pytest.mark.parametrize("tag,size", [("64", (64, 64, 64)), ("noncubic", (64, 96, 80))])
+def test_forward_against_reference_fixture(tag, size):
+    """The oracle against the REFERENCE's own outputs (oracle/make_golden.py imports /root/reference): the cubic 64^3 case and a
+    non-cubic 64x96x80 patch (reference with image_size / edge_image_size patched) -- the latter pins the size
+    generalisation (F3) every other non-cubic test relies on."""
+    g = np.load(os.path.join(GOLDEN, "model_%s.npz" % tag))
+    x, target, edge = syn.synthetic_batch([0], size)
     with torch.no_grad():
         outs, aux = rm.forward(_full_state(), x, return_aux=True)
         loss, parts = rm.total_loss(outs, target, edge)
