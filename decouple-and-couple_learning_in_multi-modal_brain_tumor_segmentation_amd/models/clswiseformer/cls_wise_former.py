@@ -7,6 +7,10 @@ Same factory (``get_cls_wise_former``), same module tree and the same 222 ``stat
 from libcwf_hip.so; there is no ATen/MIOpen compute and no CPU fallback (construction works anywhere, forward needs
 the built library and a GPU).
 
+Execution: the three sub-regions share every launch between the decouplers and the cross-region coupler (grouped kernels, the
+same-input decoupler convs as one conv); in training mode the supervision heads return lazy probability maps that the package's
+losses consume without materialising them (cwf.functional.LazyProb).
+
 Deliberate relaxations of reference limitations:
   * no ``fix_index.txt`` (F1): the row scatter is done on device from the top-k indices, with no host sync
     (the reference does 7 x 128 ``.item()`` round trips per forward, cls_wise_former.py:463-572);
@@ -86,8 +90,6 @@ class ClsWiseFormer(nn.Module):
         self.forced_index = None      # dict name -> int tensor [B,k]: teacher-forced top-k selections
         self.collect_aux = False
         self.aux = {}
-        self.parallel_regions = True  # run the three sub-region pipelines on parallel HIP streams
-        self._streams = None
         self.phase_callback = None    # set by cwf.trainer.Trainer: called with k when backward has passed cut point k (grad_phases)
 
     def grad_phases(self):
