@@ -7,7 +7,6 @@
 
 typedef struct cwf_gemm_args GemmArgs;
 
-#define GK 32
 
 // TM x TN output tile per workgroup (64 x 64: each of the 4 waves owns 2 x 2 MFMA tiles; 32 x 32: one tile per wave), K in
 // steps of 32.  The next K-tile is fetched into registers BEFORE the MFMAs of the current one are issued (software
@@ -22,7 +21,9 @@ typedef struct cwf_gemm_args GemmArgs;
 //   * rowsum of the (dropped) A operand from the workgroups of the first column tile = the bias gradient of a Linear,
 //     computed by one extra MFMA against a ones vector;
 //   * C2: the pre-activation next to the GELU output (saved for backward instead of being recomputed by a second GEMM).
-template <int TM, int TN>
+// GK = K elements staged per step (32; measured: 128 for the 32 x 32 tile and 64 for the 64 x 64 tile were 28 % / 86 % SLOWER --
+// the larger LDS tiles and register staging cost more occupancy than the fewer barriers save).
+template <int TM, int TN, int GK>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs a) {
   constexpr int LDA_S = GK + 1, LDB_S = TN + 16;
   constexpr int IM = TM / 32, JN = TN / 32;             // MFMA tiles per wave
@@ -57,11 +58,11 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs a) {
   int am[SA], ak[SA], bk[SB], bn[SB];
 #pragma unroll
   for (int i = 0; i < SA; ++i) {
-    if (a_kfast) { ak[i] = tid & 31; am[i] = (tid >> 5) + 8 * i; } else { am[i] = tid % TM; ak[i] = tid / TM + (256 / TM) * i; }
+    if (a_kfast) { ak[i] = tid % GK; am[i] = tid / GK + (256 / GK) * i; } else { am[i] = tid % TM; ak[i] = tid / TM + (256 / TM) * i; }
   }
 #pragma unroll
   for (int i = 0; i < SB; ++i) {
-    if (b_nfast) { bn[i] = tid % TN; bk[i] = tid / TN + (256 / TN) * i; } else { bk[i] = tid & 31; bn[i] = (tid >> 5) + 8 * i; }
+    if (b_nfast) { bn[i] = tid % TN; bk[i] = tid / TN + (256 / TN) * i; } else { bk[i] = tid % GK; bn[i] = tid / GK + (256 / GK) * i; }
   }
   float ra[SA], rb[SB];
   auto fetch = [&](int k0) {
@@ -161,10 +162,10 @@ extern "C" int cwf_gemm_ex(const struct cwf_gemm_args* args, void* stream) {
   const int64_t wg64 = (int64_t)cdiv(a.N, 64) * cdiv(a.M, 64) * a.ZB * a.ZH;
   if (wg64 >= 256) {
     dim3 grid(cdiv(a.N, 64), cdiv(a.M, 64), a.ZB * a.ZH);
-    hipLaunchKernelGGL((gemm_mfma_kernel<64, 64>), grid, dim3(256), 0, cwf_stream(stream), a);
+    hipLaunchKernelGGL((gemm_mfma_kernel<64, 64, 32>), grid, dim3(256), 0, cwf_stream(stream), a);
   } else {
     dim3 grid(cdiv(a.N, 32), cdiv(a.M, 32), a.ZB * a.ZH);
-    hipLaunchKernelGGL((gemm_mfma_kernel<32, 32>), grid, dim3(256), 0, cwf_stream(stream), a);
+    hipLaunchKernelGGL((gemm_mfma_kernel<32, 32, 32>), grid, dim3(256), 0, cwf_stream(stream), a);
   }
   CWF_LAUNCH_CHECK();
   return 0;

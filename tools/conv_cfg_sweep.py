@@ -6,7 +6,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch
     from cwf import functional as CF, packing as pk, kernels
     c, s, n = int(sys.argv[2]), int(sys.argv[3]), 2
-    kernels.set_precision("bf16x3")
+    prec = sys.argv[4] if len(sys.argv) > 4 else "bf16x3"
+    kernels.set_precision(prec)
     K = kernels.backend()
     x = torch.randn((n, s, s, s, c), device="cuda:0")
     w = torch.nn.Parameter(torch.randn((c, c, 3, 3, 3), device="cuda:0") * 0.05)
@@ -22,10 +23,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     for _ in range(30): run()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 30
-    print("%-8s c=%d s=%d  %.1f us  %.0f TFLOP/s" % (os.environ.get("CWF_FORCE_CFG", "auto"), c, s, ms * 1e3, 2.0 * 27 * c * c * n * s ** 3 / ms / 1e9))
+    print("%-6s %-8s c=%d s=%d  %.1f us  %.0f TFLOP/s" % (prec, os.environ.get("CWF_FORCE_CFG", "auto"), c, s, ms * 1e3, 2.0 * 27 * c * c * n * s ** 3 / ms / 1e9), flush=True)
 else:
-    for c, s in ((128, 16), (64, 32), (32, 64)):
-        for cfg in (None, "4,4,1", "2,4,2", "2,4,4", "4,2,4", "1,4,4", "1,2,4"):
-            env = dict(os.environ)
-            if cfg: env["CWF_FORCE_CFG"] = cfg
-            subprocess.run([sys.executable, os.path.abspath(__file__), "child", str(c), str(s)], env=env)
+    precs = sys.argv[1:] or ["bf16x3"]
+    for prec in precs:
+        for c, s in ((128, 16), (64, 32), (32, 64)):
+            for cfg in (None, "4,4,1", "2,4,2", "2,4,4", "4,2,4", "4,1,4", "1,4,4", "1,2,4", "1,1,4"):
+                env = dict(os.environ)
+                if cfg: env["CWF_FORCE_CFG"] = cfg
+                subprocess.run([sys.executable, os.path.abspath(__file__), "child", str(c), str(s), prec], env=env)
