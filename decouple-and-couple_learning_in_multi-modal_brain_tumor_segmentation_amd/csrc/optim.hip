@@ -143,6 +143,29 @@ extern "C" int cwf_add3(const float* a, const float* b, const float* c, float* y
   CWF_LAUNCH_CHECK();
   return 0;
 }
+__global__ void bcast3_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const float v = x[i]; y[i] = v; y[n + i] = v; y[2 * n + i] = v; }
+}
+extern "C" int cwf_bcast3(const float* x, float* y, int64_t n, void* stream) {
+  if (!x || !y || n <= 0) return CWF_E_BADARG;
+  hipLaunchKernelGGL(bcast3_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, cwf_stream(stream), x, y, n);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+__global__ void stats_channel_sum_kernel(const double* __restrict__ stats, float* __restrict__ out, int N, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int n = 0; n < N; ++n) s += stats[((int64_t)n * C + c) * 2];
+  out[c] = (float)s;
+}
+extern "C" int cwf_stats_channel_sum(const double* stats, float* out, int N, int C, void* stream) {
+  if (!stats || !out || N <= 0 || C <= 0) return CWF_E_BADARG;
+  hipLaunchKernelGGL(stats_channel_sum_kernel, dim3(cdiv(C, 64)), dim3(64), 0, cwf_stream(stream), stats, out, N, C);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
 extern "C" int cwf_channel_scale(const float* x, int x_ldc, const float* s, float* y, int y_ldc, int N, int64_t V, int C, void* stream) {
   if (!x || !s || !y || N <= 0 || V <= 0 || (C & 3) || (x_ldc & 3) || (y_ldc & 3)) return CWF_E_BADARG;
   const int64_t total = (int64_t)N * V * (C >> 2);

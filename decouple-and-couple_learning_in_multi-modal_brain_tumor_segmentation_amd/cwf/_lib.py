@@ -65,6 +65,8 @@ SIGNATURES = {
     "cwf_channel_scale": [P, I, P, P, I, I, L, I, P],
     "cwf_copy_strided": [P, I, P, I, L, I, P],
     "cwf_add3": [P, P, P, P, L, P],
+    "cwf_bcast3": [P, P, L, P],
+    "cwf_stats_channel_sum": [P, P, I, I, P],
     "cwf_gemm_ex": [P, P],
     "cwf_attn_fwd": [P, L, P, L, I, I, I, I, F, P, U64, F, P],
     "cwf_attn_bwd": [P, L, P, L, P, I, I, I, I, F, P, U64, F, P],

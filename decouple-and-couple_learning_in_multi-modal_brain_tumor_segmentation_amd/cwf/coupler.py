@@ -298,6 +298,23 @@ def add3(a, b, c):
     return _Add3Fn.apply(a, b, c)
 
 
+class _SumGroups3Fn(torch.autograd.Function):
+    """x [3, ...] -> x[0] + x[1] + x[2] (the three-region sums of the Mutual Cross-region Coupler, cls_wise_former.py:549-552); the
+    adjoint is one broadcast launch (indexing the stacked tensor would cost three zero fills, three copies and two adds in autograd)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return backend().sum_groups3(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, d):
+        return backend().bcast_groups3(d)
+
+
+def sum_groups3(x):
+    return _SumGroups3Fn.apply(x)
+
+
 class _SplitChannels3Fn(torch.autograd.Function):
     """[N,D,H,W,3C] -> three channel-slice VIEWS (no copy: the kernels take (pointer, channel stride)); the adjoint assembles the
     three slice gradients with one launch (autograd's own slice backward would be three zero fills, three copies and two adds)."""

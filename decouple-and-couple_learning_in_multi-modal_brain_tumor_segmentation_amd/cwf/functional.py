@@ -207,7 +207,7 @@ class _ConvFn(torch.autograd.Function):
             sink.mark(w)
             if sb is not None:
                 if not spec.has_bias_map:   # ConvTranspose: the bias gradient spans the 8 parity classes
-                    sb.copy_(K.in_stats(dy)[:, :, 0].sum(0))
+                    K.stats_channel_sum(K.in_stats(dy), sb)
                 sink.mark(ctx.bias_ref)
         elif ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dyv = dy[..., :spec.cout] if dy.shape[-1] != spec.cout else dy
@@ -220,7 +220,7 @@ class _ConvFn(torch.autograd.Function):
                               allow_async=once)
             dw = dwf.view(w.shape)
             if db is None:      # ConvTranspose: bias gradient spans the 8 parity classes
-                db = K.in_stats(dy)[:, :, 0].sum(0).float()
+                db = K.stats_channel_sum(K.in_stats(dy), torch.empty(spec.cout, dtype=torch.float32, device=dy.device))
         if ctx.needs_input_grad[0]:
             dxa = torch.empty(x.shape, dtype=torch.float32, device=x.device)
             fused = in_scale is not None and getattr(K, "supports_fused_norm_bwd", lambda: False)()

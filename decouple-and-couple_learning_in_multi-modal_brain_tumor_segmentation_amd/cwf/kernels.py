@@ -104,6 +104,8 @@ class HipBackend:
         self._wg_stream = {}                   # device -> side stream for weight gradients (opt-in, see wgrad_stream)
         self._wg_part = {}                     # layer key -> persistent split-K slab buffer (wgrad_to)
         self._wg_pending = []                  # descriptor rows awaiting the batched reduce (wgrad_flush)
+        self._wg_held = []                     # launches held back while wgrad_defer is set (wgrad_release)
+        self.wgrad_defer = False
         self._wg_tables = {}
         self.wgrad_async = False
         self._rng_lock = threading.Lock()      # the autograd engine may call in from its own thread
@@ -192,8 +194,10 @@ class HipBackend:
         if out is None:
             do, ho, wo = pk.out_dims(op, di, hi, wi)
             ca = out_channels_alloc or cout
-            buf = torch.zeros if ca != cout else torch.empty
-            out = buf((n, do, ho, wo, ca), dtype=_f32, device=x.device)
+            # padding channels (2-channel head logits in 4-channel rows) are NOT initialised: every consumer of such a tensor reads
+            # channels [0, cout) only (upsample_softmax, cwf_head_loss_*); the GRADIENT tensors of the same shape are written with
+            # zero padding by their producers, because the data-gradient conv does read all allocated channels
+            out = torch.empty((n, do, ho, wo, ca), dtype=_f32, device=x.device)
         y = out
         _, do, ho, wo, _ = y.shape
         y_ldc = y.stride(3)
@@ -242,7 +246,12 @@ class HipBackend:
     def wgrad_stream(self, device):
         st = self._wg_stream.get(device)
         if st is None:
-            st = torch.cuda.Stream(device=device)
+            # LOWEST priority: the data-gradient chain on the main stream is the critical path; weight-gradient workgroups should only
+            # take the CUs it leaves idle (the latency-bound deep-layer / coupler phases), not compete with it
+            import os
+            pr = os.environ.get("CWF_WGRAD_PRIORITY", "low")
+            least, greatest = torch.cuda.Stream.priority_range()
+            st = torch.cuda.Stream(device=device, priority={"low": least, "high": greatest}.get(pr, 0))
             self._wg_stream[device] = st
         return st
 
@@ -267,7 +276,19 @@ class HipBackend:
     # Gradient-sink form (cwf.optim.GradSink, used by the Trainer): the layer's split-K slabs go to a buffer of its own and the
     # reduction of ALL layers of a backward phase is one launch (wgrad_flush) that writes dW / db straight into the flat gradient
     # buffer -- no per-layer reduce launch, no per-layer gradient tensors, no concatenation before the optimizer.
+    def wgrad_release(self):
+        """Enqueue the weight-gradient launches held back since `wgrad_defer` was set (see Trainer._fwd_bwd: the decoder's
+        full-resolution weight gradients wait until backward reaches the GPU-light middle of the model, where they fill idle CUs
+        instead of competing with the decoder's own HBM-bound data gradients)."""
+        self.wgrad_defer = False
+        held, self._wg_held = self._wg_held, []
+        for args in held:
+            self.wgrad_to(*args, allow_async=True)
+
     def wgrad_to(self, key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec=None, allow_async=False):
+        if self.wgrad_async and allow_async and self.wgrad_defer:
+            self._wg_held.append((key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec))
+            return
         if self.wgrad_async and allow_async:
             side = self.wgrad_stream(x.device)
             side.wait_stream(torch.cuda.current_stream(x.device))
@@ -792,6 +813,27 @@ class HipBackend:
         o2 = out2 if out2 is not None else torch.empty((1, 1, e), dtype=_f32, device=a1.device)
         self._call("cwf_head_grad", a1.data_ptr(), c1.data_ptr(), a2.data_ptr(), c2.data_ptr(), bs, o1.data_ptr(), o2.data_ptr(), b, e, self._stream())
         return o1, o2
+
+    def sum_groups3(self, x):
+        """x [3, ...] contiguous -> x[0] + x[1] + x[2]"""
+        assert x.shape[0] == 3 and x.is_contiguous()
+        y = torch.empty(x.shape[1:], dtype=_f32, device=x.device)
+        n = y.numel()
+        self._call("cwf_add3", x.data_ptr(), x.data_ptr() + 4 * n, x.data_ptr() + 8 * n, y.data_ptr(), n, self._stream())
+        return y
+
+    def bcast_groups3(self, d):
+        """d [...] -> [3, ...] (three copies): the adjoint of sum_groups3 as ONE launch"""
+        d = d.contiguous()
+        y = torch.empty((3,) + tuple(d.shape), dtype=_f32, device=d.device)
+        self._call("cwf_bcast3", d.data_ptr(), y.data_ptr(), d.numel(), self._stream())
+        return y
+
+    def stats_channel_sum(self, stats, out):
+        """out[c] = sum_n stats[n][c][0]  (bias gradient of a transposed conv from the per-(n,c) sums of dy)"""
+        n, c, _ = stats.shape
+        self._call("cwf_stats_channel_sum", stats.data_ptr(), out.data_ptr(), n, c, self._stream())
+        return out
 
     def add3(self, a, b, c):
         a, b, c = a.contiguous(), b.contiguous(), c.contiguous()

@@ -66,6 +66,8 @@ class Trainer:
         self._eager_steps = 0
         self._graph_warmup = graph_warmup
         self._in_backward = False
+        import os
+        self.defer_decoder_wgrad = os.environ.get("CWF_DEFER_WGRAD", "1") == "1"
 
     # ------------------------------------------------------------------------------------------------
     def _phase_done(self, k):
@@ -75,6 +77,8 @@ class Trainer:
         if not self._in_backward:
             return
         K = kernels_backend()
+        if k == 0 and getattr(K, "wgrad_defer", False):
+            K.wgrad_release()          # the decoder's weight gradients start now, beside the GPU-light heads / couplers backward
         K.wgrad_flush()
         if self.overlap_comm and not _capturing():
             self._allreduce_chunk(k)
@@ -104,10 +108,14 @@ class Trainer:
         self.opt.zero_grad(set_to_none=True)
         K = kernels_backend()
         K.wgrad_async = self.wgrad_async
+        if hasattr(K, "wgrad_release"):
+            K.wgrad_defer = self.wgrad_async and self.defer_decoder_wgrad and hasattr(self.model, "phase_callback")
         self._in_backward = True
         try:
             with sink:
                 loss.backward()
+                if getattr(K, "wgrad_defer", False):
+                    K.wgrad_release()      # (no cut point fired: plain module)
                 K.wgrad_flush()            # the last phase (encoder)
         finally:
             self._in_backward = False

@@ -173,8 +173,8 @@ class ClsWiseFormer(nn.Module):
         edge = self._heads3(self.edge_supervise_label, sup_edge)   # :546
 
         # Mutual Cross-region Coupler (:549-579): post-scatter UN-gated semantic tokens are fused
-        f_tok = CP.add3(sem_tok[0], sem_tok[1], sem_tok[2])
-        f_feat = CP.add3(scat_s[0], scat_s[1], scat_s[2])
+        f_tok = CP.sum_groups3(sem_tok)
+        f_feat = CP.sum_groups3(scat_s)
         tr = self.fusion_transformer_1_2_4
         fused, f_idx = CP.FusionCouplerFn.apply(self._coupler_cfg(tr, [("fusion",)]), f_feat, f_tok, *CP.transformer_params(tr))
         if self.collect_aux:

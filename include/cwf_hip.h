@@ -389,6 +389,8 @@ int cwf_dropout_mask_rng(float* mask, int64_t n, float p, float p2, const uint64
 int cwf_mul(const float* a, const float* b, float* y, int64_t n, void* stream);
 int cwf_add(const float* a, const float* b, float* y, int64_t n, void* stream);
 int cwf_add3(const float* a, const float* b, const float* c, float* y, int64_t n, void* stream);   /* (a + b) + c: the three-region sums of the Mutual Cross-region Coupler, cls_wise_former.py:549-552 */
+int cwf_bcast3(const float* x, float* y, int64_t n, void* stream);                 /* y[g][i] = x[i], g < 3: adjoint of the three-region sums */
+int cwf_stats_channel_sum(const double* stats, float* out, int N, int C, void* stream);   /* out[c] = sum_n stats[n][c][0]: ConvTranspose bias gradient */
 int cwf_channel_scale(const float* x, int x_ldc, const float* s, float* y, int y_ldc, int N, int64_t V, int C, void* stream);
 int cwf_copy_strided(const float* x, int x_ldc, float* y, int y_ldc, int64_t nvox, int C, void* stream);
 

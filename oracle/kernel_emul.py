@@ -534,6 +534,16 @@ class EmulBackend:
     def add3(self, a, b, c):
         return (a + b) + c
 
+    def sum_groups3(self, x):
+        return (x[0] + x[1]) + x[2]
+
+    def bcast_groups3(self, d):
+        return d.unsqueeze(0).expand((3,) + tuple(d.shape)).contiguous()
+
+    def stats_channel_sum(self, stats, out):
+        out.copy_(stats[:, :, 0].sum(0).float())
+        return out
+
     # ------------------------------------------------------------------ K8/K10
     def upsample_softmax(self, logit, c, scale):
         up = F.interpolate(_ncdhw(logit[..., :c]), scale_factor=scale, mode="trilinear", align_corners=False)
