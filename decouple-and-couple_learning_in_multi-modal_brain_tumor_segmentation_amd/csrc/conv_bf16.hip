@@ -944,7 +944,12 @@ __global__ __launch_bounds__(512) void conv16s_kernel(const ConvArgsB a, const C
       constexpr int PH = decltype(PH_)::value;
       asm volatile("s_barrier" ::: "memory");            // rows of tile t are complete
       f32x4 acc[4];
-      u32x4_t fa[2][4], fl[2][4]; uint4 fb[2];
+      // LDS-read lookahead in K-steps.  Split operands: one step (12 MFMAs = 192 cycles per step cover the read latency, and two
+      // more fragment sets would not fit the 256-VGPR budget).  Single-bf16 operands (the data-gradient launches): 4 MFMAs = 64
+      // cycles per step do NOT cover it -- the wave stalled on every step (PMC: MFMA busy 15 %, LDS busy 16 %) -- so the reads run
+      // two steps ahead there, in the registers the lo fragments do not need.
+      constexpr int LA = X3 ? 1 : 2, NB = LA + 1;
+      u32x4_t fa[NB][4], fl[X3 ? NB : 1][4]; uint4 fb[NB];
       auto load_step = [&](int s_, int b_) __attribute__((always_inline)) {
         if (X3) fb[b_] = wl[s_ * 64];
         const int ta = c16_tap(2 * s_);
@@ -971,17 +976,18 @@ __global__ __launch_bounds__(512) void conv16s_kernel(const ConvArgsB a, const C
 #pragma unroll
           for (int i = 0; i < 4; ++i) { yo[i] = yofs[i]; asm volatile("" : "+v"(yo[i])); }
         }
-        load_step(0, 0);
+#pragma unroll
+        for (int s0 = 0; s0 < LA; ++s0) load_step(s0, s0);
 #pragma unroll
         for (int s = 0; s < 14; ++s) {
-          if (s + 1 < 14) load_step(s + 1, (s + 1) & 1);
+          if (s + LA < 14) load_step(s + LA, (s + LA) % NB);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][m]), __builtin_bit_cast(bf16x8, bh[s]), s == 0 ? bias4 : acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[s % NB][m]), __builtin_bit_cast(bf16x8, bh[s]), s == 0 ? bias4 : acc[m], 0, 0, 0);
             if (X3) {
-              acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][m]), __builtin_bit_cast(bf16x8, fb[s & 1]), acc[m], 0, 0, 0);
-              acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fl[s & 1][m]), __builtin_bit_cast(bf16x8, bh[s]), acc[m], 0, 0, 0);
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[s % NB][m]), __builtin_bit_cast(bf16x8, fb[s % NB]), acc[m], 0, 0, 0);
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fl[X3 ? s % NB : 0][m]), __builtin_bit_cast(bf16x8, bh[s]), acc[m], 0, 0, 0);
             }
             if (PEND != 0 && s < 4) {
               char* ybm = reinterpret_cast<char*>(prev_yb + (int64_t)s * g.Wo * g.y_ldc);
