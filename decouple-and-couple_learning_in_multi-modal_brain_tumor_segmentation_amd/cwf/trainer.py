@@ -67,7 +67,7 @@ class Trainer:
         self._graph_warmup = graph_warmup
         self._in_backward = False
         import os
-        self.defer_decoder_wgrad = os.environ.get("CWF_DEFER_WGRAD", "1") == "1"
+        self.defer_decoder_wgrad = os.environ.get("CWF_DEFER_WGRAD", "0") == "1"      # experiment switch (no measurable effect: DESIGN.md section 4)
 
     # ------------------------------------------------------------------------------------------------
     def _phase_done(self, k):
