@@ -91,6 +91,8 @@ SIGNATURES = {
     "cwf_window_to_tokens_g": [P, I, P, I, I, I, I, I, I, I, I, I, P],
     "cwf_tokens_to_window_g": [P, P, I, I, I, I, I, I, I, I, I, I, P],
     "cwf_cat3_channels": [P, P, P, P, L, I, P],
+    "cwf_stitch_windows": [P, P, I, P],
+    "cwf_argmax_dice": [P, L, L, L, P, P, P, I, L, P],
     "cwf_rng_advance": [P, P],
     "cwf_dropout_mask_rng": [P, L, F, F, P, U64, P],
 }

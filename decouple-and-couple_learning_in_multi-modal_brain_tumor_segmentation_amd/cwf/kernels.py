@@ -920,6 +920,44 @@ class HipBackend:
                    ctypes.addressof(dptrs), ldc, ws.data_ptr(), n, d, h, w, scale, self._stream())
         return dls
 
+    # ------------------------------------------------------------------ N1 (sliding-window inference glue)
+    def stitch_windows(self, out8, nb):
+        """out8: the model's output for the 8 windows stacked along the batch, logical [8*nb,4,128,128,128] over channels-last memory
+        -> stitched [nb,4,240,240,155] (predict_overlap.py:49-58, incl. the depth-axis offset quirk)"""
+        w = out8.permute(0, 2, 3, 4, 1)
+        if not w.is_contiguous():
+            w = w.contiguous()
+        assert tuple(w.shape) == (8 * nb, 128, 128, 128, 4)
+        y = torch.empty((nb, 4, 240, 240, 155), dtype=_f32, device=out8.device)
+        self._call("cwf_stitch_windows", w.data_ptr(), y.data_ptr(), nb, self._stream())
+        return y
+
+    def argmax_dice(self, prob, target=None):
+        """prob [B,4,...] (any strides with one voxel stride) -> (seg int64 [B,...], [WT, TC, ET] Dice tensor or None)"""
+        b = prob.shape[0]
+        sp = tuple(prob.shape[2:])
+        v = 1
+        for d in sp:
+            v *= d
+        if prob.is_contiguous():
+            sb, sc, sv = 4 * v, v, 1
+        elif prob.permute(0, 2, 3, 4, 1).is_contiguous():
+            sb, sc, sv = 4 * v, 1, 4
+        else:
+            prob = prob.contiguous(); sb, sc, sv = 4 * v, v, 1
+        seg = torch.empty((b,) + sp, dtype=torch.int64, device=prob.device)
+        counts = None
+        if target is not None:
+            target = target.contiguous()
+            assert target.dtype == torch.int64 and tuple(target.shape) == (b,) + sp
+            counts = torch.zeros((3, 3), dtype=torch.int64, device=prob.device)
+        self._call("cwf_argmax_dice", prob.data_ptr(), sb, sc, sv, _p(target), seg.data_ptr(), _p(counts), b, v, self._stream())
+        dice = None
+        if counts is not None:
+            c = counts.double()
+            dice = (2 * c[:, 0] + 1e-8) / (c[:, 1] + c[:, 2] + 1e-8)          # tools.dice_score (utils/tools.py:44-47)
+        return seg, dice
+
     # ------------------------------------------------------------------ K11 / misc
     def adam(self, table, ntensors, max_n, lr, beta1, beta2, eps, wd, step, amsgrad, hyper_dev=None, grad_scale=1.0):
         self._call("cwf_adam_amsgrad_scaled", table.data_ptr(), ntensors, max_n, lr, beta1, beta2, eps, wd, step, int(amsgrad),

@@ -28,6 +28,9 @@ def tailor_and_concat(x, missing_modal, model, target=None, batched=True):
     if batched:
         nb = x.shape[0]
         out = model(torch.cat(wins, dim=0), missing_modal)[0]
+        if out.is_cuda and out.dtype == torch.float32 and tuple(out.shape[1:]) == (4, 128, 128, 128) and x.shape[-1] >= 155:
+            from cwf.kernels import backend
+            return backend().stitch_windows(out, nb)          # one launch (cwf_stitch_windows) instead of clone + 8 slice copies
         t = [out[i * nb:(i + 1) * nb] for i in range(8)]
     else:
         t = [model(w, missing_modal)[0] for w in wins]
@@ -79,6 +82,11 @@ def validate_softmax(x, target, model, deterministic=True, use_TTA=False):
             prob = tailor_and_concat(x, None, model)
     finally:
         model.Unet_list.InitConv.dropout = saved
+    if prob.is_cuda and prob.dtype == torch.float32 and prob.dim() == 5 and prob.shape[1] == 4:
+        from cwf.kernels import backend                     # argmax + WT/TC/ET counts in one launch (cwf_argmax_dice)
+        tgt = None if target is None else target[..., :155].long()
+        seg, d = backend().argmax_dice(prob, tgt)
+        return seg, prob, (None if d is None else [d[0], d[1], d[2]])
     seg = prob.argmax(1)
     dice = tools.softmax_output_dice(seg, target[..., :155]) if target is not None else None
     return seg, prob, dice

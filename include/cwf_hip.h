@@ -359,6 +359,18 @@ int cwf_dice_ce_bwd(const float* prob, const int64_t* label, uint32_t posmask, c
                     float* dprob, int N, int64_t V, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * N1  sliding-window inference glue   predict_overlap.py:31-58 (tailor_and_concat), :134-141 + utils/tools.py:44-47,89-109
+ * ---------------------------------------------------------------------------------------------- */
+/* y [B][4][240][240][155] (NCDHW) <- the eight 128^3 window outputs windows[(w*B + b)][128][128][128][4] (channels-last, the model's
+ * own output memory), w in the reference's window order; hard overwrite by the later window incl. the reference's last-axis offset
+ * quirk (voxels 123..149 of the second depth window land at 128..154).  Replaces x.clone() + eight slice assignments.              */
+int cwf_stitch_windows(const float* windows, float* y, int B, void* stream);
+/* seg[b][v] = argmax over the 4 classes of prob[b*sb + c*sc + v*sv] (first maximum); with a target (int64 labels 0..3) also the
+ * counts[k][3] += (|o & t|, |o|, |t|) of tools.softmax_output_dice's three regions k = WT, TC, ET (uint64, zeroed by the caller)   */
+int cwf_argmax_dice(const float* prob, int64_t sb, int64_t sc, int64_t sv, const int64_t* target, int64_t* seg, uint64_t* counts,
+                    int B, int64_t V, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K11 fused Adam (amsgrad, L2 weight decay in the gradient)  torch.optim.Adam as used at train_no_amp.py:136,239
  *   table: device array of cwf_adam_desc; one launch updates every parameter.
  * ---------------------------------------------------------------------------------------------- */

@@ -163,8 +163,16 @@ def test_sliding_window_predictor_matches_oracle_stitching(hip):
         assert float((y - ref).abs().max()) < 1e-5
         w0 = rm.forward(syn.det_state_dict(rm.param_shapes()), x[..., :128, :128, :128])[0]
     assert float((y[..., :128, :128, :128] - w0).abs().max()) < 1e-3
-    seg, prob, dice = po.validate_softmax(x.to(DEV), torch.randint(0, 4, (1, 240, 240, 155)).to(DEV), m)
+    tgt = torch.randint(0, 4, (1, 240, 240, 155))
+    seg, prob, dice = po.validate_softmax(x.to(DEV), tgt.to(DEV), m)
     assert seg.shape == (1, 240, 240, 155) and len(dice) == 3
+    # device-side argmax + WT/TC/ET counts (cwf_argmax_dice) == torch.argmax + tools.softmax_output_dice (utils/tools.py:89-109)
+    from utils import tools
+    assert torch.equal(seg.cpu(), prob.cpu().argmax(1))
+    want = tools.softmax_output_dice(prob.cpu().argmax(1), tgt)
+    assert all(abs(float(a) - float(b)) < 1e-6 for a, b in zip(dice, want))      # (the torch expression divides in float32)
+    seg2, d2 = hip.argmax_dice(m(x[..., :128, :128, :128].to(DEV), None)[0], None)      # channels-last view, no target
+    assert d2 is None and seg2.shape == (1, 128, 128, 128)
 
 
 def test_config4_patch_160x192x160_vs_reference_and_trains(hip):
