@@ -176,8 +176,8 @@ def cpu_baseline(steps=3, dev=None, precision="bf16x3"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (100 x 23 ms: a timed region long enough for 1 Hz GPU-busy samplers)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=2, help="rank-local batch (independent B=1 samples, SURVEY F2)")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -165,6 +165,12 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x, w, b, spec, in_scale, in_shift, slope, residual, out_scale, want_stats, carry):
         K = backend()
         ctx.set_materialize_grads(False)     # (autograd would zero-FILL a gradient for each of the (scale, shift) outputs: 2 launches per conv)
+        if spec.dev is not None and x.device != spec.dev:
+            # packed weights, index maps and kernel attributes of a layer live on ONE device; a multi-device nn.DataParallel replica
+            # would launch with another device's pointers (a GPU memory fault): one process per GPU is the supported layout
+            raise RuntimeError("this conv layer's packed weights live on %s but its input is on %s: multi-device replicas inside one "
+                               "process (nn.DataParallel over several GPUs) are not supported; use one process per GPU (INTEGRATION.md)"
+                               % (spec.dev, x.device))
         n = x.shape[0]
         spec.uses += 1
         stats = K.new_stats(n, spec.cout, x.device) if want_stats else None
