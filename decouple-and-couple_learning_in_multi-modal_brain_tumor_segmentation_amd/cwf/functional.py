@@ -162,9 +162,10 @@ class WeightPacker:
 # ======================================================================================================
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, spec, in_scale, in_shift, slope, residual, out_scale, want_stats, carry):
+    def forward(ctx, x, w, b, spec, in_scale, in_shift, slope, residual, out_scale, want_stats, carry, x_link):
         K = backend()
         ctx.set_materialize_grads(False)     # (autograd would zero-FILL a gradient for each of the (scale, shift) outputs: 2 launches per conv)
+        ctx.x_link = x_link
         if spec.dev is not None and x.device != spec.dev:
             # packed weights, index maps and kernel attributes of a layer live on ONE device; a multi-device nn.DataParallel replica
             # would launch with another device's pointers (a GPU memory fault): one process per GPU is the supported layout
@@ -195,7 +196,7 @@ class _ConvFn(torch.autograd.Function):
     def backward(ctx, dy, _a, _b, dcarry):
         K = backend()
         if dy is None:                       # y itself unused downstream: only the carried alias has a gradient
-            return dcarry, None, None, None, None, None, None, None, None, None, None
+            return dcarry, None, None, None, None, None, None, None, None, None, None, None
         x, w, in_scale, in_shift, out_scale = ctx.saved_tensors
         spec = ctx.spec
         if out_scale is not None:
@@ -240,10 +241,18 @@ class _ConvFn(torch.autograd.Function):
                 K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op)
                 dx = K.in_bwd(dxa, x, in_scale, in_shift, ctx.slope, dx_add=dcarry)
             else:
-                dx = K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op, residual=dcarry)
+                link = ctx.x_link
+                if link is not None and not link.shared and getattr(K, "supports_fused_norm_bwd", lambda: False)():
+                    # x is the output of a block tail act(IN(g)) + r whose only consumer is this conv: dx (carry included) is the
+                    # tail's dL/dy, so the epilogue also accumulates the tail's InstanceNorm-backward sums
+                    link.sums = K.new_stats(x.shape[0], spec.cin, x.device)
+                    dx = K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op, residual=dcarry,
+                                stats=link.sums, nb=(link.g, link.scale, link.shift, link.slope))
+                else:
+                    dx = K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op, residual=dcarry)
         elif dcarry is not None:
             dx = dcarry
-        return dx, dw, db, None, None, None, None, dres, None, None, None
+        return dx, dw, db, None, None, None, None, dres, None, None, None, None
 
 
 class _FusedConvFn(torch.autograd.Function):
@@ -308,28 +317,56 @@ def conv(x, w, b, spec, in_norm=None, slope=1.0, residual=None, out_scale=None, 
     Returns (y, (scale_y, shift_y) or None), with carry=True (y, stats, x_alias): use x_alias for every further use of x
     (see _ConvFn.forward)."""
     sc, sh = in_norm if in_norm is not None else (None, None)
-    y, s1, s2, xc = _ConvFn.apply(x, w, b, spec, sc, sh, float(slope), residual, out_scale, want_stats, carry)
+    link = getattr(x, "_cwf_link", None)
+    if link is not None:
+        if link.claimed or in_norm is not None:
+            link.shared = True                       # a second consumer (or a normalising one): the tail keeps its own reduction
+        link.claimed = True
+        if link.shared:
+            link = None
+    y, s1, s2, xc = _ConvFn.apply(x, w, b, spec, sc, sh, float(slope), residual, out_scale, want_stats, carry, link)
     st = (s1, s2) if want_stats else None
     return (y, st, xc) if carry else (y, st)
 
 
+class NaaLink:
+    """Connects a block tail y = act(IN(g)) + x (norm_act_add) with the ONE conv that consumes y: that conv's data gradient
+    produces dL/dy, and its epilogue can accumulate the two InstanceNorm-backward sums of the tail (sum dy act', sum dy act' ghat)
+    while the values are in registers -- the tail's backward then skips its reduction pass over (dy, g)."""
+    __slots__ = ("g", "scale", "shift", "slope", "sums", "claimed", "shared")
+
+    def __init__(self, g, scale, shift, slope):
+        self.g, self.scale, self.shift, self.slope = g, scale, shift, slope
+        self.sums, self.claimed, self.shared = None, False, False
+
+
 class _NormActAddFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, scale, shift, slope, residual):
+    def forward(ctx, x, scale, shift, slope, residual, link):
         ctx.slope = slope
         ctx.has_res = residual is not None
+        ctx.link = link
         ctx.save_for_backward(x, scale, shift)
         return backend().norm_act_add(x, scale, shift, slope, residual)
 
     @staticmethod
     def backward(ctx, dy):
         x, scale, shift = ctx.saved_tensors
-        dx = backend().in_bwd(dy, x, scale, shift, ctx.slope)
-        return dx, None, None, None, (dy if ctx.has_res else None)
+        link = ctx.link
+        if link is not None and link.sums is not None and not link.shared:
+            sums, link.sums = link.sums, None        # from the consuming conv's data-gradient epilogue (this backward pass)
+            dx = backend().in_bwd_apply(dy, x, scale, shift, ctx.slope, sums)
+        else:
+            dx = backend().in_bwd(dy, x, scale, shift, ctx.slope)
+        return dx, None, None, None, (dy if ctx.has_res else None), None
 
 
 def norm_act_add(x, stats, slope, residual=None):
-    return _NormActAddFn.apply(x, stats[0], stats[1], float(slope), residual)
+    link = NaaLink(x, stats[0], stats[1], float(slope)) if torch.is_grad_enabled() else None
+    y = _NormActAddFn.apply(x, stats[0], stats[1], float(slope), residual, link)
+    if link is not None:
+        y._cwf_link = link                           # picked up by the conv that takes y as its (un-normalised) input
+    return y
 
 
 class _CatFn(torch.autograd.Function):
