@@ -202,12 +202,18 @@ def main():
     rehearse = os.environ.get("CWF_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
-    if world > 1:
+    # CWF_FORCE_COMM=1 under a one-rank launcher (RANK set): a one-rank RCCL group, so that the collective path (comm stream,
+    # per-phase all-reduce) runs and can be profiled on a one-GPU box.  The printed line is then marked "comm_forced".
+    forced = world == 1 and "RANK" in os.environ and os.environ.get("CWF_FORCE_COMM", "0") in ("1", "init")
+    use_dist = world > 1 or forced
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearse:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            opts = dist.ProcessGroupNCCL.Options()
+            opts.is_high_priority_stream = True          # RCCL's own stream in the high-priority queue pool, off the compute streams' queues
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -229,7 +235,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -245,7 +251,7 @@ def main():
     host_dt = time.perf_counter() - t0                   # host enqueue time (no sync): ~ dt means launch-bound
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -275,11 +281,13 @@ def main():
         }
         out["roofline"] = dominant_kernel_roofline(dev, args.precision)
         log("roofline leg done: %s" % json.dumps(out["roofline"]))
+        if forced:
+            out["comm_forced"] = True                    # one-rank RCCL group: the collective path ran (CWF_FORCE_COMM=1)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], extra = cpu_baseline(args.cpu_steps, dev, args.precision)
             out.update(extra)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

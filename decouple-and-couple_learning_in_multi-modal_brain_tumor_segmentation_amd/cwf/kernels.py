@@ -88,6 +88,25 @@ _raw_stream = torch._C._cuda_getCurrentRawStream
 _current_device = torch._C._cuda_getDevice
 
 
+def _priority_stream(device, which):
+    """A stream of the lowest ("low") / highest ("high") priority the HIP runtime offers ("normal": torch's default pool).
+    torch.cuda.Stream.priority_range() reports (0, -1) on ROCm -- no low priority -- so "low" goes to the runtime directly."""
+    if which == "normal":
+        return torch.cuda.Stream(device=device)
+    if which == "high":
+        return torch.cuda.Stream(device=device, priority=torch.cuda.Stream.priority_range()[1])
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    least, greatest = ctypes.c_int(0), ctypes.c_int(0)
+    with torch.cuda.device(device):
+        if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0 or least.value <= 0:
+            return torch.cuda.Stream(device=device, priority=torch.cuda.Stream.priority_range()[1])   # no low level: any non-default pool
+        h = ctypes.c_void_p()
+        if hip.hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), ctypes.c_int(least.value)) != 0:   # 1 = hipStreamNonBlocking
+            raise RuntimeError("hipStreamCreateWithPriority failed")
+    return torch.cuda.ExternalStream(h.value, device=device)
+
+
 class HipBackend:
     name = "hip"
 
@@ -246,12 +265,15 @@ class HipBackend:
     def wgrad_stream(self, device):
         st = self._wg_stream.get(device)
         if st is None:
-            # LOWEST priority: the data-gradient chain on the main stream is the critical path; weight-gradient workgroups should only
-            # take the CUs it leaves idle (the latency-bound deep-layer / coupler phases), not compete with it
+            # A NON-default priority, for the hardware queue it brings rather than for the scheduling: the HIP runtime multiplexes
+            # all streams of one priority over a small pool of hardware queues, and once other streams exist (RCCL creates
+            # several at communicator init) a default-priority side stream lands on the MAIN stream's queue -- the weight
+            # gradients then run strictly between the main stream's kernels (measured: zero overlap, 87.7 -> 78.5 volumes/s
+            # with nothing but a one-rank process group alive).  Each priority has its own queue pool.  "low" is also the
+            # right scheduling hint: the data-gradient chain on the main stream is the critical path.
             import os
             pr = os.environ.get("CWF_WGRAD_PRIORITY", "low")
-            least, greatest = torch.cuda.Stream.priority_range()
-            st = torch.cuda.Stream(device=device, priority={"low": least, "high": greatest}.get(pr, 0))
+            st = _priority_stream(device, pr)
             self._wg_stream[device] = st
         return st
 

@@ -4,11 +4,11 @@
     -> backward -> gradient average over ranks -> Adam(amsgrad) with the poly learning rate (:183,270-273).
 
 Execution modes:
-  * eager (default): every kernel is launched from Python (~2000 launches, ~26 ms of host time per step, hidden behind the GPU);
-    the three sub-region pipelines run on parallel HIP streams.
+  * eager (default): every kernel is launched from Python (~460 launches, ~16-21 ms of host time per step, hidden behind the GPU's
+    ~23 ms); the three sub-regions share each launch (grouped kernels), weight gradients run on a side stream.
   * graph: forward + losses + backward + gradient flattening are captured ONCE into a hipGraph (torch.cuda.graph) and replayed
-    per step (host cost ~1 ms).  Shapes are static (fixed patch size, per-sample top-k of fixed k) and the token selection runs
-    on device, so nothing in the step needs the host.  Currently slower end to end than eager (the captured branches overlap less).
+    per step.  Shapes are static (fixed patch size, per-sample top-k of fixed k), the token selection and the dropout counters live
+    on device, so nothing in the step needs the host.  Slower end to end than eager on this ROCm build.
 Gradients never exist as per-parameter tensors: backward kernels write them into ONE flat buffer laid out in backward-completion
 order (cwf.optim.GradSink; the conv weight gradients through one batched split-K reduce per phase), which the fused Adam launch reads.
 Multi-GPU gradient averaging (the only data-path collective) is overlapped with backward: the model fires a callback when backward
@@ -16,8 +16,12 @@ has passed a cut point (decoder done / everything but the encoder done, ClsWiseF
 (9.8 MB, then 43 MB) is all-reduced (RCCL, summed; Adam reads g / world) on a communication stream that waits for the producing
 streams -- the three region streams and the weight-gradient side stream stay in use -- while the encoder's backward (~7 ms) runs;
 only the last 14 MB slice is exposed.  Under graph replay the collective follows the replay (4 chunks of the flat buffer).
+CWF_FORCE_COMM=1 keeps the whole collective path on at world size 1 (a one-rank RCCL group): the way to exercise and profile it on a
+one-GPU box.
 Checkpoints use the reference layout {'epoch', 'state_dict' with 'module.' prefix, 'optim_dict'} (:248-253)."""
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.distributed as dist
@@ -47,16 +51,21 @@ class Trainer:
         phases = model.grad_phases() if hasattr(model, "grad_phases") else None
         self.opt = FusedAdam(model.parameters(), lr=lr, weight_decay=weight_decay, amsgrad=amsgrad, phases=phases)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # collectives on: more than one rank, or a one-rank group with CWF_FORCE_COMM=1 (exercises the RCCL path on a one-GPU box)
+        self.comm = self.world > 1 or (dist.is_available() and dist.is_initialized() and os.environ.get("CWF_FORCE_COMM", "0") == "1")
         self.opt.grad_scale = 1.0 / self.world          # the all-reduce SUMS; Adam reads g / world (the DDP average, train_no_amp.py:133)
         self.use_graph = use_graph
         self.cuda = next(model.parameters()).is_cuda
         # weight gradients on a side stream (they are leaves of backward; the data-gradient chain is its critical path)
         self.wgrad_async = bool(wgrad_async) and self.cuda
         # all-reduce of a phase's slice as soon as backward has passed its cut point (not under graph capture)
-        self.overlap_comm = bool(overlap_comm) and self.world > 1 and not use_graph
-        self._comm_stream = torch.cuda.Stream() if (self.overlap_comm and self.cuda) else None
+        self.overlap_comm = bool(overlap_comm) and self.comm and not use_graph
+        # HIGH priority: its own hardware-queue pool (a default-priority stream can land on the main stream's queue, see
+        # cwf.kernels._priority_stream), and a collective should start the moment its slice is final
+        self._comm_stream = (torch.cuda.Stream(priority=torch.cuda.Stream.priority_range()[1])
+                             if (self.overlap_comm and self.cuda) else None)
         self._works = []
-        if self.world > 1:
+        if self.comm:
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, 0)
         if hasattr(model, "phase_callback"):
@@ -66,7 +75,6 @@ class Trainer:
         self._eager_steps = 0
         self._graph_warmup = graph_warmup
         self._in_backward = False
-        import os
         self.defer_decoder_wgrad = os.environ.get("CWF_DEFER_WGRAD", "0") == "1"      # experiment switch (no measurable effect: DESIGN.md section 4)
 
     # ------------------------------------------------------------------------------------------------
@@ -128,7 +136,7 @@ class Trainer:
         return loss.detach(), [p.detach() for p in parts]
 
     def _finish_comm(self):
-        if self.world == 1:
+        if not self.comm:
             return
         if self.overlap_comm and self._graph is None:
             for w in self._works:

@@ -7,7 +7,11 @@ from cwf import kernels
 from cwf.trainer import Trainer
 from models.clswiseformer.cls_wise_former import get_cls_wise_former
 from utils import synthetic as syn
-kernels.set_precision("bf16x3")
+kernels.set_precision("bf16x3", wgrad="bf16", dgrad="bf16")
+if os.environ.get("CWF_PROFILE_PG") == "1":          # with a one-rank RCCL process group alive (does it slow the host down?)
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 dev = torch.device("cuda:0")
 m = get_cls_wise_former(dataset="brats", _conv_repr=True, _pe_type="fixed").to(dev).train()
 tr = Trainer(m)
@@ -15,6 +19,12 @@ x, target, edge = syn.synthetic_batch([0, 1], (128, 128, 128))
 x, target, edge = x.to(dev), target.to(dev), edge.to(dev)
 for _ in range(3):
     tr.step(x, target, edge, 0)
+torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+for _ in range(10):
+    tr.step(x, target, edge, 0)
+print("host enqueue ms/step (no profiler): %.2f" % ((time.perf_counter() - t0) * 100))
 torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
