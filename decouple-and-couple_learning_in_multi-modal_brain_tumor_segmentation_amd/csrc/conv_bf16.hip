@@ -1306,6 +1306,256 @@ static int launch_conv16(const ConvArgsB& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Pointwise family: 1x1x1 convs (forward and data gradient, CWF_CONV1) and the ConvTranspose k = 2, s = 2 forward (CWF_CONVT2:
+// eight 1x1x1 convs, one per output parity class, of the SAME input voxel).  An output voxel depends on ONE input voxel: there is
+// no halo and no reuse across taps, so staging through LDS (what conv_bf16_kernel does for every op) only costs -- these layers
+// are pure streams (0.3-8 FLOP/B) and ran at 17-29 % of the HBM rate in the generic kernel (1x1 32->16 @128^3: 346 us for
+// 805 MB; tools/layer_table.py).  Here a wave streams 16-voxel groups straight from global memory INTO MFMA fragments:
+//   * the MFMA runs as  D[co][voxel] = W[co][ci] * X[ci][voxel]  (weights are the A operand): lane (r, kq) then needs 8
+//     consecutive input channels of voxel r -- two float4 loads, a wave reads 16 voxels x 128 B contiguous -- and holds four
+//     consecutive OUTPUT channels of voxel r, one float4 store (the generic kernel's D layout gives 16 dword stores);
+//   * bf16 (hi, lo) split, bias / residual / statistics / norm-backward statistics epilogue all in registers; the loads of G = 2..4
+//     groups (x, residual, nb_x) are issued together, then the groups are computed and stored;
+//   * weights: read from the SAME packed buffer as the generic kernel (block (chunk, tile): lane (kq, r) = channels
+//     chunk*16 + (kq&1)*8.., column r), permuted by index into the A layout; in registers for one class, in LDS for eight;
+//   * a workgroup stays inside one sample: per-sample parameters are loaded once and the statistics leave through LDS as ONE
+//     coalesced fp64 atomic instruction per workgroup; no LDS traffic per voxel, no barrier in the loop; 64-140 VGPRs.
+// Semantics identical to conv_bf16_kernel for what it takes (v = acc + bias + residual; statistics of v or the norm-backward
+// pair); launches with a normalising prologue or an out_scale stay on the generic kernel (pw_eligible).
+// ---------------------------------------------------------------------------------------------------
+struct PwWork { int Vin, gps, wps, gpw; };              // input voxels per sample, 16-voxel groups per sample, workgroups per sample, groups per wave
+
+template <bool X3, int KS, int NT, int NCLS, int EPI>
+__global__ __launch_bounds__(256) void pw_conv_kernel(const ConvArgsB a, const PwWork wk) {
+  constexpr bool HAS_RES = (EPI & 1) != 0, HAS_NB = (EPI & 2) != 0;
+  constexpr int G = (KS * NT <= 1) ? 4 : 2;              // groups per iteration: all their loads are in flight together
+  extern __shared__ float4 lds4[];
+  __shared__ float red[4][NT * 16][2];
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = (int)blockIdx.x / wk.wps, wg = (int)blockIdx.x % wk.wps;      // a workgroup stays inside ONE sample
+  const int gA = (wg * 4 + wave) * wk.gpw;
+  const int gB = min(gA + wk.gpw, wk.gps);
+
+  // ---- weights
+  uint4 wh[NCLS == 1 ? KS : 1][NT], wl[NCLS == 1 ? KS : 1][NT];
+  const int wlane = ((kq & 1) * 16 + r) * 2;              // uint4 index of this lane's (hi, lo) pair inside a packed block
+  if (NCLS == 1) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int chunk = 2 * s + (kq >> 1);
+        wh[s][t] = make_uint4(0, 0, 0, 0); wl[s][t] = make_uint4(0, 0, 0, 0);
+        if (chunk < g.nchunks) {
+          const uint4* p = a.wpk + ((int64_t)chunk * g.ntiles + t) * 128 + wlane;
+          wh[s][t] = p[0];
+          if (X3) wl[s][t] = p[1];
+        }
+      }
+  } else {
+    // all eight classes' packed blocks, verbatim ([cls][chunk][tile][lane][hi|lo]), into LDS
+    const int n4 = NCLS * g.nchunks * g.ntiles * 128;
+    for (int i = tid; i < n4; i += 256) lds4[i] = reinterpret_cast<const float4*>(a.wpk)[i];
+    __syncthreads();
+  }
+
+  // ---- per-sample bases and parameters
+  const float* xs = a.x + (int64_t)n * wk.Vin * g.x_ldc;
+  const float* rs = HAS_RES ? a.residual + (int64_t)n * wk.Vin * a.r_ldc : nullptr;
+  const float* ns = HAS_NB ? a.nb_x + (int64_t)n * wk.Vin * a.nb_ldc : nullptr;
+  float* ys = a.y + (int64_t)n * g.Do * g.Ho * g.Wo * g.y_ldc;
+  f32x4 nsc4[NT], nsh4[NT], bias4[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int cb = t * 16 + kq * 4;
+    bias4[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.bias && cb < g.Cout) bias4[t] = *reinterpret_cast<const f32x4*>(a.bias + cb);
+    if (HAS_NB && cb < g.Cout) {
+      nsc4[t] = *reinterpret_cast<const f32x4*>(a.nb_scale + (int64_t)n * g.Cout + cb);
+      nsh4[t] = *reinterpret_cast<const f32x4*>(a.nb_shift + (int64_t)n * g.Cout + cb);
+    }
+  }
+  f32x4 s1[NT], s2[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { s1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; s2[t] = s1[t]; }
+  const bool has_stats = a.stats != nullptr;
+
+  for (int gi = gA; gi < gB; gi += G) {
+    // ---- loads of G groups: x (8 input channels per K-step), residual / nb_x (4 output channels per tile)
+    f32x4 xv[G][KS][2], rv[HAS_RES ? G : 1][NT], nv[HAS_NB ? G : 1][NT];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const bool ok = gi + k < gB;                        // wave-uniform
+      const int vox = (gi + k) * 16 + r;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int c0 = s * 32 + kq * 8;
+        xv[k][s][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; xv[k][s][1] = xv[k][s][0];
+        if (ok && c0 < g.Cin) xv[k][s][0] = *reinterpret_cast<const f32x4*>(xs + (int64_t)vox * g.x_ldc + c0);
+        if (ok && c0 + 4 < g.Cin) xv[k][s][1] = *reinterpret_cast<const f32x4*>(xs + (int64_t)vox * g.x_ldc + c0 + 4);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int cb = t * 16 + kq * 4;
+        if (HAS_RES && ok && cb < g.Cout) rv[k][t] = *reinterpret_cast<const f32x4*>(rs + (int64_t)vox * a.r_ldc + cb);
+        if (HAS_NB && ok && cb < g.Cout) nv[k][t] = *reinterpret_cast<const f32x4*>(ns + (int64_t)vox * a.nb_ldc + cb);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const bool ok = gi + k < gB;
+      const int v0 = (gi + k) * 16;
+      // ---- B fragments: x -> bf16 hi (, lo)   (no layer of this family has a normalising prologue: pw_eligible)
+      uint4 bh[KS], bl[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        unsigned h[4], l[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v0_ = xv[k][s][j >> 1][(2 * j) & 3], v1_ = xv[k][s][j >> 1][(2 * j + 1) & 3];
+          if (X3) split_bf16(v0_, v1_, h[j], l[j]);
+          else h[j] = pack_bf16(v0_, v1_);
+        }
+        bh[s] = make_uint4(h[0], h[1], h[2], h[3]); bl[s] = make_uint4(l[0], l[1], l[2], l[3]);
+      }
+      int od = 0, oh = 0, ow = 0;
+      if (NCLS > 1) { ow = v0 % g.Wi; const int t2 = v0 / g.Wi; oh = t2 % g.Hi; od = t2 / g.Hi; }
+#pragma unroll 1
+      for (int cls = 0; cls < NCLS; ++cls) {
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          acc[t] = bias4[t];
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            uint4 ah, al;
+            if (NCLS == 1) { ah = wh[s][t]; al = wl[s][t]; }
+            else {
+              const int chunk = 2 * s + (kq >> 1);
+              ah = make_uint4(0, 0, 0, 0); al = ah;
+              if (chunk < g.nchunks) {
+                const uint4* p = reinterpret_cast<const uint4*>(lds4) + ((cls * g.nchunks + chunk) * g.ntiles + t) * 128 + wlane;
+                ah = p[0];
+                if (X3) al = p[1];
+              }
+            }
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh[s]), acc[t], 0, 0, 0);
+            if (X3) {
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl[s]), acc[t], 0, 0, 0);
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh[s]), acc[t], 0, 0, 0);
+            }
+          }
+        }
+        // ---- epilogue: lane (r, kq) holds output channels t*16 + kq*4 .. +3 of voxel r
+        int64_t ovox;
+        if (NCLS == 1) ovox = v0 + r;
+        else ovox = ((int64_t)(2 * od + (cls >> 2)) * g.Ho + 2 * oh + ((cls >> 1) & 1)) * g.Wo + 2 * (ow + r) + (cls & 1);
+        float* yp = ys + ovox * g.y_ldc + kq * 4;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int cb = t * 16 + kq * 4;
+          if (ok && cb < g.Cout) {
+            f32x4 v = acc[t];
+            if (HAS_RES) v += rv[HAS_RES ? k : 0][t];
+            *reinterpret_cast<f32x4*>(yp + t * 16) = v;
+            if (HAS_NB) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const float h = fmaf(nv[HAS_NB ? k : 0][t][i], nsc4[t][i], nsh4[t][i]);
+                const float gn = v[i] * (h > 0.f ? 1.f : a.nb_slope);
+                s1[t][i] += gn; s2[t][i] = fmaf(gn, h, s2[t][i]);
+              }
+            } else if (has_stats) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) { s1[t][i] += v[i]; s2[t][i] = fmaf(v[i], v[i], s2[t][i]); }
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- statistics: lanes -> wave (shuffles over r) -> workgroup (LDS) -> ONE coalesced fp64 atomic instruction per workgroup
+  // (an atomic costs per instruction, not per lane: thousands of 4-lane atomics on the same two cache lines serialise in L2)
+  if (has_stats) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float u1 = s1[t][i], u2 = s2[t][i];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { u1 += __shfl_xor(u1, o, 64); u2 += __shfl_xor(u2, o, 64); }
+        if (r == 0) { red[wave][t * 16 + kq * 4 + i][0] = u1; red[wave][t * 16 + kq * 4 + i][1] = u2; }
+      }
+    __syncthreads();
+    if (tid < NT * 16 * 2) {
+      const int co = tid >> 1, which = tid & 1;
+      const double s = (double)red[0][co][which] + (double)red[1][co][which] + (double)red[2][co][which] + (double)red[3][co][which];
+      if (co < g.Cout) atomic_add_f64(a.stats + ((int64_t)n * g.Cout + co) * 2 + which, s);
+    }
+  }
+}
+
+template <bool X3, int KS, int NT, int NCLS, int EPI>
+static int launch_pw(const ConvArgsB& a, hipStream_t st) {
+  const ConvGeom& g = a.g;
+  constexpr int G = (KS * NT <= 1) ? 4 : 2;
+  PwWork wk;
+  wk.Vin = g.Di * g.Hi * g.Wi;
+  wk.gps = wk.Vin >> 4;
+  // ~2048 workgroups in all (8 per CU), each inside one sample; a wave takes a contiguous run of groups, a multiple of G
+  int wps = 2048 / g.N; if (wps < 1) wps = 1;
+  const int maxw = cdiv(wk.gps, 4 * G);
+  if (wps > maxw) wps = maxw;
+  wk.gpw = cdiv(cdiv(wk.gps, wps * 4), G) * G;
+  wk.wps = cdiv(wk.gps, wk.gpw * 4);
+  const size_t lds = NCLS == 1 ? 0 : (size_t)NCLS * g.nchunks * g.ntiles * 2048;
+  hipLaunchKernelGGL((pw_conv_kernel<X3, KS, NT, NCLS, EPI>), dim3((unsigned)(wk.wps * g.N)), dim3(256), lds, st, a, wk);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+
+// Is (op, shape, epilogue) one the pointwise kernel takes?  (anything else: the generic kernel)
+static bool pw_eligible(int op, const ConvArgsB& a, int* ks, int* nt) {
+  const ConvGeom& g = a.g;
+  if (op != CWF_CONV1 && op != CWF_CONVT2) return false;
+  static const bool off = getenv("CWF_NO_POINTWISE") != nullptr;          // A/B switch (diagnostics)
+  if (off) return false;
+  const int64_t Vin = (int64_t)g.Di * g.Hi * g.Wi;
+  if ((Vin & 15) || Vin * (g.x_ldc > g.y_ldc * 8 ? g.x_ldc : g.y_ldc * 8) >= (1ll << 31)) return false;
+  if ((g.Cout & 3) || (g.y_ldc & 3) || ((uintptr_t)a.y & 15)) return false;
+  if (a.bias && ((uintptr_t)a.bias & 15)) return false;
+  if (a.in_scale || a.out_scale) return false;             // (no 1x1x1 / transposed layer of the model has either)
+  if (a.residual && ((a.r_ldc & 3) || ((uintptr_t)a.residual & 15))) return false;
+  if (a.nb_x && ((a.nb_ldc & 3) || ((uintptr_t)a.nb_x & 15) || ((uintptr_t)a.nb_scale & 15) || ((uintptr_t)a.nb_shift & 15))) return false;
+  *ks = cdiv(g.Cin, 32); *nt = cdiv(g.Cout, 16);
+  if (*nt != g.ntiles) return false;
+  const bool shape_ok = (*ks == 1 && (*nt == 1 || *nt == 2 || *nt == 4)) || (*ks == 2 && *nt == 2);
+  if (!shape_ok) return false;
+  if (op == CWF_CONVT2) {
+    if ((g.Wi & 15) || a.residual || a.nb_x || *nt > 2 || *ks > 1) return false;
+  }
+  return true;
+}
+
+template <bool X3>
+static int dispatch_pw(int op, const ConvArgsB& a, hipStream_t st, int ks, int nt) {
+  if (op == CWF_CONVT2) {
+    if (nt == 1) return launch_pw<X3, 1, 1, 8, 0>(a, st);
+    return launch_pw<X3, 1, 2, 8, 0>(a, st);
+  }
+  const int epi = (a.residual ? 1 : 0) | (a.nb_x ? 2 : 0);
+#define CWF_PW(k, t) if (ks == k && nt == t) { \
+    switch (epi) { case 0: return launch_pw<X3, k, t, 1, 0>(a, st); case 1: return launch_pw<X3, k, t, 1, 1>(a, st); \
+                   case 2: return launch_pw<X3, k, t, 1, 2>(a, st); default: return launch_pw<X3, k, t, 1, 3>(a, st); } }
+  CWF_PW(1, 1) CWF_PW(1, 2) CWF_PW(1, 4) CWF_PW(2, 2)
+#undef CWF_PW
+  return CWF_E_BADARG;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // weight packing: dst[(i/8)*16 + i%8] = hi(src[map[i]]), dst[(i/8)*16 + 8 + i%8] = lo(...)   (bf16, zeros where map < 0)
 // ---------------------------------------------------------------------------------------------------
 __global__ void gather_split_bf16_kernel(const cwf_gather_desc* __restrict__ table) {
@@ -1418,6 +1668,12 @@ extern "C" int cwf_conv_mfma_bf16_nb(int op, int x3, const float* x, int x_ldc, 
   a.nb_x = nb_x; a.nb_ldc = nb_ldc; a.nb_scale = nb_scale; a.nb_shift = nb_shift; a.nb_slope = nb_slope;
   a.diag = nullptr; a.diag_mode = 0;
   hipStream_t st = cwf_stream(stream);
+  {
+    int ks, nt;
+    if (pw_eligible(op, a, &ks, &nt)) {                   // 1x1x1 / ConvTranspose streams: no LDS staging (pw_conv_kernel)
+      return x3 ? dispatch_pw<true>(op, a, st, ks, nt) : dispatch_pw<false>(op, a, st, ks, nt);
+    }
+  }
   if (op == CWF_CONV3_S1 && Cin <= 16 && Cout <= 16) {      // these layers are packed in conv16's tap order (c16_tap)
     int nat[27];
     for (int t = 0; t < 27; ++t) nat[t] = a.g.tapofs[t];

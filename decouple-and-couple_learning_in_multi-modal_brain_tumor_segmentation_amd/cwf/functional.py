@@ -162,7 +162,7 @@ class WeightPacker:
 # ======================================================================================================
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, spec, in_scale, in_shift, slope, residual, out_scale, want_stats, carry, x_link):
+    def forward(ctx, x, w, b, spec, in_scale, in_shift, slope, residual, out_scale, want_stats, carry, x_link, out=None):
         K = backend()
         ctx.set_materialize_grads(False)     # (autograd would zero-FILL a gradient for each of the (scale, shift) outputs: 2 launches per conv)
         ctx.x_link = x_link
@@ -175,8 +175,9 @@ class _ConvFn(torch.autograd.Function):
         n = x.shape[0]
         spec.uses += 1
         stats = K.new_stats(n, spec.cout, x.device) if want_stats else None
+        # out: a channel slice of a wider buffer (the conv writes its half of a concatenation in place: no copy launch)
         y = K.conv(spec.op, x, spec.packed(False), b, spec.cout, in_scale, in_shift, slope, residual, out_scale, stats,
-                   w_ref=w, out_channels_alloc=spec.cout_alloc)
+                   out=out, w_ref=w, out_channels_alloc=spec.cout_alloc)
         ctx.spec, ctx.slope = spec, slope
         ctx.bias_ref = b
         ctx.has_res = residual is not None
@@ -196,7 +197,7 @@ class _ConvFn(torch.autograd.Function):
     def backward(ctx, dy, _a, _b, dcarry):
         K = backend()
         if dy is None:                       # y itself unused downstream: only the carried alias has a gradient
-            return dcarry, None, None, None, None, None, None, None, None, None, None, None
+            return dcarry, None, None, None, None, None, None, None, None, None, None, None, None
         x, w, in_scale, in_shift, out_scale = ctx.saved_tensors
         spec = ctx.spec
         if out_scale is not None:
@@ -252,7 +253,7 @@ class _ConvFn(torch.autograd.Function):
                     dx = K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op, residual=dcarry)
         elif dcarry is not None:
             dx = dcarry
-        return dx, dw, db, None, None, None, None, dres, None, None, None, None
+        return dx, dw, db, None, None, None, None, dres, None, None, None, None, None
 
 
 class _FusedConvFn(torch.autograd.Function):
@@ -312,10 +313,10 @@ def fused_conv3(x, convs, spec):
     return y, (sc, sh)
 
 
-def conv(x, w, b, spec, in_norm=None, slope=1.0, residual=None, out_scale=None, want_stats=False, carry=False):
+def conv(x, w, b, spec, in_norm=None, slope=1.0, residual=None, out_scale=None, want_stats=False, carry=False, out=None):
     """y = conv(act(IN(x)))(+bias)(+residual)(*out_scale).  in_norm = (scale, shift) of x or None.
     Returns (y, (scale_y, shift_y) or None), with carry=True (y, stats, x_alias): use x_alias for every further use of x
-    (see _ConvFn.forward)."""
+    (see _ConvFn.forward).  out: write y into this [N,D,H,W,cout] view (a channel slice of a concatenation buffer, see cat_into)."""
     sc, sh = in_norm if in_norm is not None else (None, None)
     link = getattr(x, "_cwf_link", None)
     if link is not None:
@@ -324,7 +325,7 @@ def conv(x, w, b, spec, in_norm=None, slope=1.0, residual=None, out_scale=None, 
         link.claimed = True
         if link.shared:
             link = None
-    y, s1, s2, xc = _ConvFn.apply(x, w, b, spec, sc, sh, float(slope), residual, out_scale, want_stats, carry, link)
+    y, s1, s2, xc = _ConvFn.apply(x, w, b, spec, sc, sh, float(slope), residual, out_scale, want_stats, carry, link, out)
     st = (s1, s2) if want_stats else None
     return (y, st, xc) if carry else (y, st)
 
@@ -387,6 +388,31 @@ class _CatFn(torch.autograd.Function):
 
 def cat_channels(a, b):
     return _CatFn.apply(a, b)
+
+
+class _CatIntoFn(torch.autograd.Function):
+    """concat(a, b) where b was WRITTEN by its producer into the upper channels of `buf` (conv(..., out=buf[..., ca:])): only a is
+    copied.  The gradient splits into two channel-slice views (no copy), exactly like _CatFn."""
+    @staticmethod
+    def forward(ctx, a, b, buf):
+        ca = a.shape[-1]
+        assert b.data_ptr() == buf[..., ca:].data_ptr() and buf.shape[-1] == ca + b.shape[-1] and b.stride(3) == buf.stride(3)
+        backend().copy_into(a, buf[..., :ca])
+        ctx.ca = ca
+        return buf.view(buf.shape)
+
+    @staticmethod
+    def backward(ctx, d):
+        return d[..., :ctx.ca], d[..., ctx.ca:], None
+
+
+def cat_buffer(a, cb):
+    """an uninitialised [N,D,H,W,Ca+cb] buffer for cat_into; hand buf[..., Ca:] to the producer of the second operand"""
+    return torch.empty(a.shape[:-1] + (a.shape[-1] + cb,), dtype=torch.float32, device=a.device)
+
+
+def cat_into(a, b, buf):
+    return _CatIntoFn.apply(a, b, buf)
 
 
 # ======================================================================================================

@@ -241,8 +241,9 @@ class DeUp_Cat(nn.Module):
 
     def forward(self, x, prev):
         t, _ = self.conv1(x)
-        u, _ = self.conv2(t)
-        y, _ = self.conv3(CF.cat_channels(prev, u))
+        buf = CF.cat_buffer(prev, self.conv2.spec.cout)
+        u, _ = self.conv2(t, out=buf[..., prev.shape[-1]:])       # the transposed conv writes its half of the concatenation in place
+        y, _ = self.conv3(CF.cat_into(prev, u, buf))
         return y
 
 

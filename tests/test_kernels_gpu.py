@@ -152,6 +152,61 @@ def test_fused_norm_backward_sums(hip, op, cin, cout, size, n, prec):
     close(dx_fused, dx_two_pass.cpu(), rtol=2e-5, what="fused norm backward")
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("op,cin,cout,size,n", [
+    (pk.CONV1, 32, 16, (8, 8, 32), 2),           # DeUp conv3 (concat -> C)
+    (pk.CONV1, 16, 4, (4, 4, 16), 3),            # endconv; waves span samples (stats flush / per-sample reload inside a wave)
+    (pk.CONV1, 16, 32, (8, 8, 16), 2),           # two output tiles
+    (pk.CONV1, 4, 16, (4, 8, 8), 3),             # 4 input channels (endconv's data gradient): second float4 masked
+    (pk.CONV1, 64, 32, (8, 8, 16), 1),           # two K-steps x two tiles
+    (pk.CONV1, 48, 16, (4, 4, 16), 2),           # partial second K-step
+    (pk.CONV1, 20, 12, (4, 4, 16), 2),           # channel counts that are multiples of 4 only
+    (pk.CONVT2, 16, 16, (4, 6, 16), 2),          # eight parity classes from LDS-resident weights
+    (pk.CONVT2, 32, 32, (4, 4, 32), 1),
+])
+def test_pointwise_stream_kernel(hip, op, cin, cout, size, n, prec):
+    """pw_conv_kernel (conv_bf16.hip): 1x1x1 convs and the ConvTranspose forward as register-level streams.  The epilogue
+    combinations that reach it (bias / residual / statistics; norm-backward sums on data gradients) against the oracle
+    emulation; launches with a prologue or out_scale stay on the generic kernel (test_conv_family_fwd_dgrad_wgrad)."""
+    tol = PREC_TOL[prec]
+    from cwf import functional as CF
+    d, h, w_ = size
+    x = rnd(n, d, h, w_, cin, seed=21)
+    wshape = (cin, cout, 2, 2, 2) if op == pk.CONVT2 else (cout, cin, 1, 1, 1)
+    w = rnd(*wshape, seed=22, scale=1.0 / math.sqrt(cin))
+    b = rnd(cout, seed=23, scale=0.1)
+    spec = _packed(CF.ConvSpec(op, cin, cout), w, prec)
+    do, ho, wo = pk.out_dims(op, d, h, w_)
+    res = rnd(n, do, ho, wo, cout, seed=27) if op == pk.CONV1 else None
+    st_ref = E.new_stats(n, cout, None)
+    y_ref = E.conv(op, x, None, b, cout, None, None, 1.0, res, None, st_ref, w_ref=w)
+    st = hip.new_stats(n, cout, DEV)
+    y = hip.conv(op, x.to(DEV), spec.wpk16_f, b.to(DEV), cout, None, None, 1.0, None if res is None else res.to(DEV), None, st, prec=prec)
+    close(y, y_ref, rtol=tol, what="fwd")
+    close(st, st_ref, rtol=max(1e-5, tol), what="stats")
+    # into a channel slice of a wider buffer (the concatenation buffer of DeUp_Cat), strided input
+    wide = torch.full((n, do, ho, wo, cout + 8), 7.0, device=DEV)
+    xw = torch.zeros((n, d, h, w_, cin + 4), device=DEV); xw[..., :cin] = x.to(DEV)
+    hip.conv(op, xw[..., :cin], spec.wpk16_f, b.to(DEV), cout, out=wide[..., 8:], prec=prec)
+    y_plain = E.conv(op, x, None, b, cout, w_ref=w)
+    close(wide[..., 8:], y_plain, rtol=tol, what="fwd into slice")
+    assert bool((wide[..., :8] == 7.0).all())
+    if op != pk.CONV1:
+        return
+    # data gradient (a 1x1x1 conv with the transposed weights) with a residual operand and the norm-backward sums
+    dy = rnd(n, d, h, w_, cout, seed=28)
+    carry = rnd(n, d, h, w_, cin, seed=29)
+    in_scale = rnd(n, cin, seed=24).abs() + 0.5
+    in_shift = rnd(n, cin, seed=25)
+    dx_ref = E.conv(pk.CONV1, dy, None, None, cin, out=torch.empty(n, d, h, w_, cin), w_ref=w, fwd_op=op) + carry
+    sums = hip.new_stats(n, cin, DEV)
+    xd, sc, sh = x.to(DEV), in_scale.to(DEV), in_shift.to(DEV)
+    dx = hip.conv(pk.CONV1, dy.to(DEV), spec.wpk16_d, None, cin, residual=carry.to(DEV), out=torch.empty((n, d, h, w_, cin), device=DEV),
+                  prec=prec, stats=sums, nb=(xd, sc, sh, 0.01))
+    close(dx, dx_ref, rtol=tol, what="dgrad + residual")
+    close(hip.in_bwd_apply(dx, xd, sc, sh, 0.01, sums), hip.in_bwd(dx, xd, sc, sh, 0.01).cpu(), rtol=2e-5, what="norm-backward sums")
+
+
 def test_gather_batched_matches_index_maps(hip):
     from cwf import functional as CF
     packer = CF.WeightPacker()

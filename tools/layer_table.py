@@ -1,0 +1,65 @@
+"""Per-layer table of the conv family at the bench configuration (batch 2 x 4 x 128^3): every distinct (op, Cin, Cout, extent) of the
+model's conv layers timed in isolation -- forward (bench precision: split-bf16) and data gradient (single bf16) -- against its own
+HBM floor (x read once + y written once, fp32) and MFMA floor.  Diagnostic; output quoted in DESIGN.md."""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "decouple-and-couple_learning_in_multi-modal_brain_tumor_segmentation_amd")); sys.path.insert(0, REPO)
+import torch
+from cwf import functional as CF, packing as pk, kernels
+from models.clswiseformer.cls_wise_former import get_cls_wise_former
+from models.clswiseformer.layers import HipConv
+from utils import synthetic as syn
+
+dev = torch.device("cuda:0")
+kernels.set_precision("bf16x3", wgrad="bf16", dgrad="bf16")
+K = kernels.backend()
+m = get_cls_wise_former(dataset="brats", _conv_repr=True, _pe_type="fixed").to(dev).train()
+seen = {}
+def hook(mod, args, kwargs):
+    x = args[0]
+    key = (mod.spec.op, mod.spec.cin, mod.spec.cout, tuple(x.shape[1:4]), kwargs.get("in_norm") is not None or (len(args) > 1 and args[1] is not None),
+           bool(kwargs.get("want_stats", False)))
+    seen.setdefault(key, []).append(mod)
+for mod in m.modules():
+    if isinstance(mod, HipConv):
+        mod.register_forward_pre_hook(hook, with_kwargs=True)
+x, target, edge = syn.synthetic_batch([0, 1], (128, 128, 128))
+with torch.no_grad():
+    m(x.to(dev), None)
+names = {pk.CONV3_S1: "3x3x3", pk.CONV3_S2: "3x3x3/2", pk.CONV1: "1x1x1", pk.CONVT2: "T2x2x2"}
+taps = {pk.CONV3_S1: 27, pk.CONV3_S2: 27, pk.CONV1: 1, pk.CONVT2: 1}
+
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+print("%-8s %4s %4s %-14s %3s | %8s %8s %6s %6s | %8s %6s" % ("op", "Cin", "Cout", "in extent", "n", "fwd us", "floor us", "HBM %", "MFMA %", "dgrad us", "HBM %"))
+tot_f = tot_d = 0.0
+for (op, cin, cout, ext, normed, wstats), mods in sorted(seen.items(), key=lambda kv: -kv[0][3][0] * 1000 - kv[0][1]):
+    n = 2
+    spec = mods[0].spec
+    w = mods[0].weight
+    packer = CF.WeightPacker(); packer.add(spec, w); packer.refresh()
+    xin = torch.randn((n,) + ext + (cin,), device=dev)
+    sc = torch.ones((n, cin), device=dev); sh = torch.zeros((n, cin), device=dev)
+    b = mods[0].bias
+    y = K.conv(op, xin, spec.packed(False), b, cout, sc if normed else None, sh if normed else None, 0.01, w_ref=w, out_channels_alloc=spec.cout_alloc)
+    stats = K.new_stats(n, cout, dev) if wstats else None
+    f = timeit(lambda: K.conv(op, xin, spec.packed(False), b, cout, sc if normed else None, sh if normed else None, 0.01, None, None, stats, out=y, w_ref=w))
+    dy = torch.randn_like(y); dx = torch.empty_like(xin)
+    if y.shape[-1] != cout:
+        dy[..., cout:] = 0
+    d = timeit(lambda: K.conv(pk.dgrad_op(op), dy, spec.packed(True), None, cin, out=dx, w_ref=w, fwd_op=op))
+    vin, vout = xin.numel() // cin, y.numel() // y.shape[-1]
+    byts = 4.0 * (xin.numel() + vout * cout)
+    flops = 2.0 * taps[op] * cin * cout * (vout if op != pk.CONVT2 else vout)
+    floor = byts / 8e12 * 1e6
+    mf = 3 * flops / 2.5e15 * 1e6
+    print("%-8s %4d %4d %-14s %3d | %8.1f %8.1f %6.1f %6.1f | %8.1f %6.1f" % (names[op], cin, cout, "x".join(map(str, ext)), len(mods), f, floor, 100 * floor / f, 100 * mf / f, d, 100 * floor / d), flush=True)
+    tot_f += f * len(mods); tot_d += d * len(mods)
+print("sum over layers: forward %.2f ms, data gradient %.2f ms" % (tot_f / 1e3, tot_d / 1e3))
