@@ -249,7 +249,9 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
   // fast path (workgroup/wave-uniform test): interior tile of a plain (single-class, unit output stride) geometry with all NT
   // channel tiles valid -- every store is SGPR row base + tile-invariant 32-bit lane offset, no per-element bounds or
   // 64-bit address arithmetic (cf. conv16_kernel's epilogue)
-  const bool fast = os == 1 && g.ncls == 1 && od0 + g.TD <= Dc && oh0 + g.TH <= Hc && ow0 + 16 <= Wc && (nt0 + NT) * 16 <= g.Cout &&
+  // (output-parity classes -- stride-2 data gradient, ConvTranspose -- take it too: voxel stride os = 2 and the class offset
+  // only change the row base and the per-lane voxel step; the scalar path below cost the EnDown data gradient 2x)
+  const bool fast = od0 + g.TD <= Dc && oh0 + g.TH <= Hc && ow0 + 16 <= Wc && (nt0 + NT) * 16 <= g.Cout &&
                     !(a.residual && a.out_scale);
   if (fast) {
     float bvj[NT];
@@ -270,9 +272,9 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
       float nsc[NT], nsh[NT];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {                      // opaque copies: keep the zero-extension in this block (saddr form)
-        yo[i] = (unsigned)((kq * 4 + i) * g.y_ldc + nt0 * 16 + r) * 4u; asm volatile("" : "+v"(yo[i]));
-        if (HAS_RES) { ro[i] = (unsigned)((kq * 4 + i) * a.r_ldc + nt0 * 16 + r) * 4u; asm volatile("" : "+v"(ro[i])); }
-        if (HAS_NB) { xo[i] = (unsigned)((kq * 4 + i) * a.nb_ldc + nt0 * 16 + r) * 4u; asm volatile("" : "+v"(xo[i])); }
+        yo[i] = (unsigned)((kq * 4 + i) * os * g.y_ldc + nt0 * 16 + r) * 4u; asm volatile("" : "+v"(yo[i]));
+        if (HAS_RES) { ro[i] = (unsigned)((kq * 4 + i) * os * a.r_ldc + nt0 * 16 + r) * 4u; asm volatile("" : "+v"(ro[i])); }
+        if (HAS_NB) { xo[i] = (unsigned)((kq * 4 + i) * os * a.nb_ldc + nt0 * 16 + r) * 4u; asm volatile("" : "+v"(xo[i])); }
       }
       if (HAS_NB) {
 #pragma unroll
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
       for (int m = 0; m < MT; ++m) {
         const int mt = wm * MT + m;
         const int od = od0 + mt / g.TH, oh = oh0 + mt % g.TH;
-        const int64_t vox0 = (((int64_t)n * g.Do + od) * g.Ho + oh) * g.Wo + ow0;
+        const int64_t vox0 = (((int64_t)n * g.Do + od * os + of0) * g.Ho + oh * os + of1) * g.Wo + ow0 * os + of2;
         char* yb = reinterpret_cast<char*>(a.y + vox0 * g.y_ldc);
         const char* rb = HAS_RES ? reinterpret_cast<const char*>(a.residual + vox0 * a.r_ldc) : nullptr;
         const char* xb = HAS_NB ? reinterpret_cast<const char*>(a.nb_x + vox0 * a.nb_ldc) : nullptr;

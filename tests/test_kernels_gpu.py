@@ -207,6 +207,42 @@ def test_pointwise_stream_kernel(hip, op, cin, cout, size, n, prec):
     close(hip.in_bwd_apply(dx, xd, sc, sh, 0.01, sums), hip.in_bwd(dx, xd, sc, sh, 0.01).cpu(), rtol=2e-5, what="norm-backward sums")
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+def test_parity_class_outputs_take_the_fast_epilogue(hip, prec):
+    """Eight-class launches of the generic kernel (stride-2 data gradient, ConvTranspose forward beyond the pointwise kernel's
+    shapes) on interior tiles: row-base + lane-offset stores with output voxel stride 2, residual operand, statistics and
+    norm-backward sums."""
+    tol = PREC_TOL[prec]
+    from cwf import functional as CF
+    # EnDown data gradient: 32 -> 16 channels onto a 2x finer grid, carried gradient added, sums of the block tail it feeds
+    n, cin, cout, (d, h, w_) = 2, 16, 32, (16, 16, 32)
+    w = rnd(cout, cin, 3, 3, 3, seed=32, scale=1.0 / math.sqrt(cin * 27))
+    spec = _packed(CF.ConvSpec(pk.CONV3_S2, cin, cout), w, prec)
+    do, ho, wo = pk.out_dims(pk.CONV3_S2, d, h, w_)
+    x = rnd(n, d, h, w_, cin, seed=31)
+    dy = rnd(n, do, ho, wo, cout, seed=38)
+    carry = rnd(n, d, h, w_, cin, seed=39)
+    sc, sh = (rnd(n, cin, seed=34).abs() + 0.5).to(DEV), rnd(n, cin, seed=35).to(DEV)
+    dx_ref = E.conv(pk.CONV3_S2_DGRAD, dy, None, None, cin, out=torch.empty(n, d, h, w_, cin), w_ref=w, fwd_op=pk.CONV3_S2) + carry
+    sums = hip.new_stats(n, cin, DEV)
+    dx = hip.conv(pk.CONV3_S2_DGRAD, dy.to(DEV), spec.wpk16_d, None, cin, residual=carry.to(DEV), out=torch.empty((n, d, h, w_, cin), device=DEV),
+                  prec=prec, stats=sums, nb=(x.to(DEV), sc, sh, 0.01))
+    close(dx, dx_ref, rtol=tol, what="s2 dgrad + residual")
+    close(hip.in_bwd_apply(dx, x.to(DEV), sc, sh, 0.01, sums), hip.in_bwd(dx, x.to(DEV), sc, sh, 0.01).cpu(), rtol=2e-5, what="norm-backward sums")
+    # ConvTranspose 64 -> 64 (weights too large for the pointwise kernel's LDS copy): bias + statistics
+    n, c, (d, h, w_) = 1, 64, (4, 4, 16)
+    w = rnd(c, c, 2, 2, 2, seed=42, scale=1.0 / math.sqrt(c))
+    b = rnd(c, seed=43, scale=0.1)
+    spec = _packed(CF.ConvSpec(pk.CONVT2, c, c), w, prec)
+    x = rnd(n, d, h, w_, c, seed=41)
+    st_ref = E.new_stats(n, c, None)
+    y_ref = E.conv(pk.CONVT2, x, None, b, c, None, None, 1.0, None, None, st_ref, w_ref=w)
+    st = hip.new_stats(n, c, DEV)
+    y = hip.conv(pk.CONVT2, x.to(DEV), spec.wpk16_f, b.to(DEV), c, None, None, 1.0, None, None, st, prec=prec)
+    close(y, y_ref, rtol=tol, what="convT fwd")
+    close(st, st_ref, rtol=max(1e-5, tol), what="convT stats")
+
+
 def test_gather_batched_matches_index_maps(hip):
     from cwf import functional as CF
     packer = CF.WeightPacker()
