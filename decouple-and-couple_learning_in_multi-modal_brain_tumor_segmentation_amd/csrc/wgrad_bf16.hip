@@ -10,6 +10,7 @@
 // Work split, persistent tile walk, partial-slab layout and the reduce step are those of wgrad_mfma.hip.
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -411,6 +412,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgsB a) {
 //     7 accumulators in registers across ALL tiles of the workgroup: no per-tile epilogue at all;
 //   * raw s_barrier (lgkmcnt only) hands the buffers over; one slab per workgroup at the end (reduced by cwf_wgrad_reduce).
 // ---------------------------------------------------------------------------------------------------
+#ifndef CWF_W16_DEPTH
+#define CWF_W16_DEPTH 7
+#endif
+#ifndef CWF_WS1_DEPTH
+#define CWF_WS1_DEPTH 5
+#endif
 #define W16_NVOX 648
 #define W16_XW 20                                       // LDS row pitch of the x image in voxels (18 + 2 pad), see below
 #define W16_DW 20                                       // LDS row pitch of the dy image in voxels (16 + 4 pad)
@@ -485,7 +492,10 @@ __global__ __launch_bounds__(256 + 64 * W16_LW) void wgrad16_kernel(const WgArgs
     // before its MFMA and every MFMA waits out the LDS latency).
     auto tiles = [&](auto BIAS_) {
       constexpr bool BIAS = decltype(BIAS_)::value;
-      constexpr int DEPTH = 2;
+      // LDS-read lookahead in tap steps.  Split operands: a step is 3 MFMAs = 48 cycles, two steps cover the transposed-read latency.
+      // Single-bf16 operands (what the bench runs): ONE MFMA = 16 cycles per step -- at two steps every MFMA waited out most of an
+      // LDS round trip (5.6k cycles per tile against 0.9k of MFMAs); seven steps ahead (the most the two-slot dy-fragment ring allows), in registers the lo fragments do not need.
+      constexpr int DEPTH = X3 ? 2 : CWF_W16_DEPTH;
       for (int it = 0; it < niter; ++it) {
         asm volatile("s_barrier" ::: "memory");          // buffer it&1 is complete
         bf16x8 ah[DEPTH + 1], al[DEPTH + 1], bh[2], bl[2];
@@ -697,6 +707,240 @@ __global__ __launch_bounds__(256 + 64 * W16_LW) void wgrad16_kernel(const WgArgs
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// wgrad_s1: the 3x3x3 stride-1 layers the generic kernel above used to take (32 / 64 / 128 channels; 38 launches per step, the
+// largest single item of the step's kernel time), single-bf16 operands, restructured like wgrad16_kernel.  The generic kernel
+// stages a tile with one DEPENDENT global load per staging slot (11 x slots + CGW/4 dy slots per thread: load, wait, convert,
+// store, next) and only then starts its MFMA phase: ~19 exposed round trips per tile, 4.6 us against 0.75 us of MFMAs
+// (32 ch @ 64^3: 111 us per launch under rocprofv3, tools/wgrad_micro.py).  Here a workgroup is 12 waves, one per CU:
+//   * waves 4-11 (loaders) convert tile t+1 (recomputed InstanceNorm + activation for x) into the OTHER LDS buffer, then issue ALL
+//     loads of tile t+3 (straight-line, masked by pointer select) into the register set that frees: two tiles of loads in flight
+//     (eight loader waves keep a set at 8-10 float4 per thread; with four, two sets spill and one set is latency-bound: 59 us);
+//   * waves 0-3 (MFMA) run the 56-step transposed-read / MFMA phase of tile t (wave w owns taps w, w+4, ...; slot 27 = bias row)
+//     with accumulators persistent over the workgroup's whole tile range;
+//   * one raw s_barrier per tile hands the buffers over; one slab per workgroup, fewer and longer workgroups than the generic
+//     plan (256 in all), so the slab traffic and the reduce halve as well.
+// Same (chunk, channel-group) blocking, LDS image layout (padded / skewed rows: conflict-free transposed reads) and slab layout
+// as wgrad_bf16_kernel<7, NTW, true, false>.  Measured (slab kernel, rocprofv3): 32 ch @ 64^3 111 -> 50 us, 64 ch @ 32^3 60 -> 28 us,
+// 128 ch @ 16^3 37 -> 22 us.  At 50 us the (tile, chunk) units move 300 MB of L2 -> CU traffic (x halo 41 KB + dy 32 KB each;
+// 2.2x the 134 MB the layer reads from HBM) = 6.0 TB/s -- the same aggregate ingest rate wgrad16_kernel sits at (934 MB in
+// 150 us), i.e. the CU <- L2 fabric, not the MFMA phase (a deeper LDS-read lookahead changed nothing).  What is left is traffic:
+// both chunks of a tile against one dy fetch, a sliding halo.
+// ---------------------------------------------------------------------------------------------------
+#define WS1_LW 8                                        // loader waves (MFMA waves: 4) -> 768-thread workgroups
+template <int NTW>
+__global__ __launch_bounds__(256 + 64 * WS1_LW) void wgrad_s1_kernel(const WgArgsB a) {
+  constexpr int CG = NTW, CGW = CG * 16;
+  constexpr int XW = 20, DP = CGW == 16 ? 20 : 16, DSK = CGW == 32 ? 16 : 0;
+  constexpr int XIMG = 36 * XW * 16;                                   // bf16 elements of the x image
+  constexpr int DIMG = 16 * DP * CGW + (16 / 2 + 1) * DSK;             // bf16 elements of the dy image
+  constexpr unsigned BUFB = (unsigned)(XIMG + DIMG) * 2u;              // bytes of one buffer (x | dy)
+  static_assert(BUFB % 16 == 0, "buffer pitch");
+  static_assert(CWF_WS1_DEPTH < 8 && CWF_W16_DEPTH < 8, "the dy fragment of K-step ks+2 reuses the registers of K-step ks");
+  extern __shared__ float4 lds4[];
+  const ConvGeom& g = a.g;
+  unsigned short* lds = reinterpret_cast<unsigned short*>(lds4);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x;
+  const int chunk = blockIdx.y / a.ngroups, grp = blockIdx.y % a.ngroups;
+  const int co0 = grp * CGW;
+  const int tiles_sp = g.tiles_d * g.tiles_h * g.tiles_w;
+  const int t_begin = split * a.tiles_per_split;
+  const int t_end = min(a.total_tiles, t_begin + a.tiles_per_split);
+  const int niter = max(t_end - t_begin, 0);
+
+  if (wave < 4) {
+    // =============================================================== MFMA waves
+    const int kq = lane >> 4, bq = (lane & 15) >> 2, bp = lane & 3;
+    f32x4 acc[7][NTW];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
+    const bool bias_wave = wave == 3;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds4;
+    const unsigned lane_x = lds_base + (((kq & 1) * XW + (kq >> 1) * 8 + bq) * 16 + bp * 4) * 2;
+    unsigned xa0[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int t = wave + 4 * i;
+      xa0[i] = lane_x + (t < 27 ? (((t / 9) * 6 + (t / 3) % 3) * XW + t % 3) * 32 : 0);
+    }
+    const unsigned da0 = lds_base + XIMG * 2 + (((kq & 1) * DP + (kq >> 1) * 8 + bq) * CGW + (kq & 1) * DSK + bp * 4) * 2;
+    auto trf = [&](unsigned addr, unsigned second) __attribute__((always_inline)) {   // two transposed reads -> one K fragment
+      const s16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)addr);
+      const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(addr + second));
+      const s16x8 w = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+      return __builtin_bit_cast(bf16x8, w);
+    };
+    for (int it = 0; it < niter; ++it) {
+      asm volatile("s_barrier" ::: "memory");              // buffer it & 1 is complete
+      const unsigned bo = (it & 1) ? BUFB : 0u;
+      unsigned xa[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) xa[i] = xa0[i] + bo;
+      const unsigned da = da0 + bo;
+      constexpr int DEPTH = CWF_WS1_DEPTH;               // tap steps of LDS-read lookahead (a step is NTW MFMAs = 16-32 cycles)
+      bf16x8 ah[DEPTH + 1], bh[2][NTW];
+      auto issue = [&](int f) __attribute__((always_inline)) {   // f = ks * 7 + i, compile-time after unrolling
+        const int ks = f / 7, i = f % 7;
+        if (i == 0) {
+          const unsigned od_ = (2 * ks * DP * CGW + ks * DSK) * 2;
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) bh[ks & 1][j] = trf(da + od_ + j * 32, 4 * CGW * 2);
+        }
+        const unsigned ox = (((ks >> 1) * 6 + ((2 * ks) & 3)) * XW) * 32;
+        ah[f % (DEPTH + 1)] = trf(xa[i] + ox, 4 * 32);
+      };
+#pragma unroll
+      for (int f = 0; f < DEPTH; ++f) issue(f);
+#pragma unroll
+      for (int f = 0; f < 56; ++f) {
+        if (f + DEPTH < 56) issue(f + DEPTH);
+        __builtin_amdgcn_sched_barrier(0);
+        const int ks = f / 7, i = f % 7;
+        bf16x8 ahf = ah[f % (DEPTH + 1)];
+        if (i == 6) ahf = bias_wave ? ones : ahf;            // wave 3: tap slot 27 = bias row (ones . dy); wave-uniform select
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahf, bh[ks & 1][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- slab (layout of wgrad_bf16_kernel: block = (chunk, group, tap, tile))
+    float4* out = reinterpret_cast<float4*>(a.partial + (int64_t)split * a.slab_floats);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int t = wave + 4 * i;
+      if (t > 27) continue;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int64_t blk = (((int64_t)chunk * a.ngroups + grp) * 28 + t) * CG + j;
+        out[blk * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    }
+  } else {
+    // =============================================================== loader waves
+    const int lt = tid - 256;
+    constexpr int LT = 64 * WS1_LW;                         // loader threads
+    constexpr int VPP = LT / 4;                             // x voxels staged per pass (4 threads per voxel)
+    constexpr int XS = (648 + VPP - 1) / VPP;               // 6 x staging slots per loader thread
+    constexpr int DSL = CGW / 4;                            // channel quads per dy voxel
+    constexpr int DS = 256 * DSL / LT;                      // 2 (16 output channels) or 4 (32) dy staging slots per loader thread
+    constexpr int DROWS = LT / DSL / 16;                    // M-tile rows covered by one dy slot over all loader threads
+    static_assert(256 * DSL % LT == 0 && LT / DSL % 16 == 0, "dy slots are whole M-tile rows");
+    const int q = lt & 3;
+    const int c = chunk * 16 + q * 4;
+    const bool cval = c < g.Cin;
+    const bool has_norm = a.in_scale != nullptr;
+    const bool plain = !has_norm && a.in_slope == 1.f;
+    int relx[XS];
+    unsigned xo[XS];                                        // LDS element offset | (idd, ih, iw) << 16 (bounds tests per tile)
+#pragma unroll
+    for (int i = 0; i < XS; ++i) {
+      int v = (lt >> 2) + VPP * i; if (v > 647) v = 647;    // (last slot: 8 real voxels; the rest re-read the last one)
+      const int iw = v % 18, t2 = v / 18, ih = t2 % 6, idd = t2 / 6;
+      relx[i] = ((idd * g.Hi + ih) * g.Wi + iw) * g.x_ldc + c;
+      xo[i] = (unsigned)((t2 * XW + iw) * 16 + q * 4) | ((unsigned)idd << 16) | ((unsigned)ih << 19) | ((unsigned)iw << 22);
+    }
+    // dy slot k of this thread: element e = lt + LT k -> voxel e / DSL, channel quad e % DSL: slot k is slot 0 moved by DROWS whole
+    // M-tile rows -- per-thread base + wave-uniform increments
+    const int vox0 = lt / DSL, cq0 = lt % DSL, m0 = vox0 >> 4, tw = vox0 & 15;
+    const int reld0 = (((m0 >> 2) * g.Ho + (m0 & 3)) * g.Wo + tw) * a.dy_ldc + co0 + cq0 * 4;
+    const bool last_x = (lt >> 2) + VPP * (XS - 1) < 648;   // the last slot holds a real voxel for this thread
+    const bool co_ok = co0 + cq0 * 4 < g.Cout;
+    // TWO register sets of loads in flight (a tile period is shorter than one memory round trip under load); eight loader waves
+    // keep a set at XS + DS = 8..10 float4 per thread
+    float4 vx[2][XS], vd[2][DS], sc[2], sh[2];
+    unsigned okx[2] = {0u, 0u}, okd[2] = {0u, 0u};
+    sc[0] = sc[1] = make_float4(1.f, 1.f, 1.f, 1.f); sh[0] = sh[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto issue = [&](int tile, auto S) __attribute__((always_inline)) {
+      constexpr int SET = decltype(S)::value;
+      const int n = tile / tiles_sp; int rem = tile % tiles_sp;
+      const int tile_w = rem % g.tiles_w; rem /= g.tiles_w;
+      const int tile_h = rem % g.tiles_h; const int tile_d = rem / g.tiles_h;
+      const int od0 = tile_d * 4, oh0 = tile_h * 4, ow0 = tile_w * 16;
+      const int id0 = od0 - 1, ih0 = oh0 - 1, iw0 = ow0 - 1;
+      const float* xb = a.x + ((((int64_t)n * g.Di + id0) * g.Hi + ih0) * g.Wi + iw0) * g.x_ldc;
+      const float* db = a.dy + ((((int64_t)n * g.Do + od0) * g.Ho + oh0) * g.Wo + ow0) * a.dy_ldc;
+      if (has_norm && cval) {
+        sc[SET] = *reinterpret_cast<const float4*>(a.in_scale + (int64_t)n * g.Cin + c);
+        sh[SET] = *reinterpret_cast<const float4*>(a.in_shift + (int64_t)n * g.Cin + c);
+      }
+      unsigned mx = 0, md = 0;
+#pragma unroll
+      for (int i = 0; i < XS; ++i) {
+        const int gd = id0 + (int)((xo[i] >> 16) & 7u), gh = ih0 + (int)((xo[i] >> 19) & 7u), gw = iw0 + (int)(xo[i] >> 22);
+        const bool ok = cval && (i < XS - 1 || last_x) && (unsigned)gd < (unsigned)g.Di && (unsigned)gh < (unsigned)g.Hi && (unsigned)gw < (unsigned)g.Wi;
+        vx[SET][i] = *reinterpret_cast<const float4*>(ok ? xb + relx[i] : a.x);      // unconditional load, masked at conversion
+        mx |= ok ? (1u << i) : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < DS; ++k) {
+        const int m = m0 + k * DROWS;
+        const bool ok = co_ok && od0 + (m >> 2) < g.Do && oh0 + (m & 3) < g.Ho && ow0 + tw < g.Wo;
+        const int rel = reld0 + ((((m >> 2) - (m0 >> 2)) * g.Ho + ((m & 3) - (m0 & 3))) * g.Wo) * a.dy_ldc;
+        vd[SET][k] = *reinterpret_cast<const float4*>(ok ? db + rel : a.dy);
+        md |= ok ? (1u << k) : 0u;
+      }
+      okx[SET] = mx; okd[SET] = md;
+    };
+    auto commit = [&](int buf, auto S) __attribute__((always_inline)) {
+      constexpr int SET = decltype(S)::value;
+      unsigned short* xh = lds + (buf ? BUFB / 2 : 0);
+      unsigned short* dh = xh + XIMG;
+#pragma unroll
+      for (int i = 0; i < XS; ++i) {
+        if (i == XS - 1 && !last_x) continue;
+        float4 val = vx[SET][i];
+        if (!plain) {
+          val.x = cwf_act(val.x * sc[SET].x + sh[SET].x, a.in_slope); val.y = cwf_act(val.y * sc[SET].y + sh[SET].y, a.in_slope);
+          val.z = cwf_act(val.z * sc[SET].z + sh[SET].z, a.in_slope); val.w = cwf_act(val.w * sc[SET].w + sh[SET].w, a.in_slope);
+        }
+        uint2 h; h.x = pk_bf16(val.x, val.y); h.y = pk_bf16(val.z, val.w);
+        const bool was = (okx[SET] >> i) & 1u;              // zero padding applies after the activation
+        h.x = was ? h.x : 0u; h.y = was ? h.y : 0u;
+        *reinterpret_cast<uint2*>(xh + (xo[i] & 0xffffu)) = h;
+      }
+#pragma unroll
+      for (int k = 0; k < DS; ++k) {
+        const int m = m0 + k * DROWS;
+        const float4 val = vd[SET][k];
+        uint2 h; h.x = pk_bf16(val.x, val.y); h.y = pk_bf16(val.z, val.w);
+        const bool was = (okd[SET] >> k) & 1u;
+        h.x = was ? h.x : 0u; h.y = was ? h.y : 0u;
+        *reinterpret_cast<uint2*>(dh + (m * DP + tw) * CGW + ((m + 1) >> 1) * DSK + cq0 * 4) = h;
+      }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    // tile u lives in register set u & 1 and LDS buffer u & 1.  Iteration it: tile it+1 is converted right after the barrier, then
+    // tile it+3 is requested into the set it frees (tile it+2 is already in flight in the other set)
+    if (niter > 0) {
+      issue(t_begin, S0{});
+      commit(0, S0{});
+      if (niter > 1) issue(t_begin + 1, S1{});
+      if (niter > 2) issue(t_begin + 2, S0{});
+    }
+    for (int it = 0; it < niter; it += 2) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (it + 1 < niter) {
+        commit(1, S1{});
+        if (it + 3 < niter) issue(t_begin + it + 3, S1{});
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (it + 2 < niter) {
+          commit(0, S0{});
+          if (it + 4 < niter) issue(t_begin + it + 4, S0{});
+        }
+      }
+    }
+  }
+}
+
 // plan: identical decisions to wgrad_mfma.hip (the Python side sizes the workspace through cwf_wgrad_nsplit / _slab_floats)
 extern "C" int cwf_wgrad_nsplit(int op, int N, int Do, int Ho, int Wo, int Cin, int Cout);
 extern "C" int64_t cwf_wgrad_slab_floats(int op, int Cin, int Cout);
@@ -745,6 +989,32 @@ extern "C" int cwf_wgrad_mfma_bf16(int op, int x3, const float* x, int x_ldc, co
     CWF_LAUNCH_CHECK();
     if (nsplit_used) *nsplit_used = grid;
     return 0;
+  }
+  if (!x3 && op == CWF_CONV3_S1 && CG <= 2 && a.g.TD == 4 && a.g.TH == 4 && a.g.ID == 6 && a.g.IH == 6 && a.g.IW == 18 && (Cout & 3) == 0 &&
+      (dy_ldc & 3) == 0 && (((uintptr_t)dy) & 15) == 0) {
+    static const bool off = getenv("CWF_NO_WGRAD_S1") != nullptr;       // A/B switch (diagnostics)
+    if (!off) {
+      // producer / consumer kernel: ~256 eight-wave workgroups in all (one per CU), each a contiguous tile range of one (chunk, group)
+      int want1 = 256 / nblk; if (want1 < 1) want1 = 1; if (want1 > total) want1 = total;
+      const int tps1 = cdiv(total, want1), splits1 = cdiv(total, tps1);
+      if (splits1 <= wg_splits) {                          // (the workspace was sized for wg_splits slabs)
+        a.tiles_per_split = tps1;
+        if (nsplit_used) *nsplit_used = splits1;
+        const size_t lds1 = (size_t)2 * (36 * 20 * 16 + 16 * (CG == 1 ? 20 : 16) * CG * 16 + (16 / 2 + 1) * (CG == 2 ? 16 : 0)) * sizeof(unsigned short);
+        dim3 grid1(splits1, nchunks * ngroups, 1);
+        hipStream_t st1 = cwf_stream(stream);
+        static bool attr1 = false;
+        if (!attr1) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_s1_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_s1_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          attr1 = true;
+        }
+        if (CG == 1) hipLaunchKernelGGL((wgrad_s1_kernel<1>), grid1, dim3(256 + 64 * WS1_LW), lds1, st1, a);
+        else hipLaunchKernelGGL((wgrad_s1_kernel<2>), grid1, dim3(256 + 64 * WS1_LW), lds1, st1, a);
+        CWF_LAUNCH_CHECK();
+        return 0;
+      }
+    }
   }
   const size_t ximg = (size_t)a.g.ID * a.g.IH * wg_x_pitch(a.g.IW, a.g.is) * 16;
   const size_t dimg = (size_t)a.g.TD * a.g.TH * wg_dy_pitch(CG * 16) * CG * 16 + (size_t)(a.g.TD * a.g.TH / 2 + 1) * wg_dy_skew(CG * 16);

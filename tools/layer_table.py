@@ -38,8 +38,8 @@ def timeit(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
-print("%-8s %4s %4s %-14s %3s | %8s %8s %6s %6s | %8s %6s" % ("op", "Cin", "Cout", "in extent", "n", "fwd us", "floor us", "HBM %", "MFMA %", "dgrad us", "HBM %"))
-tot_f = tot_d = 0.0
+print("%-8s %4s %4s %-14s %3s | %8s %8s %6s %6s | %8s %6s | %8s %6s" % ("op", "Cin", "Cout", "in extent", "n", "fwd us", "floor us", "HBM %", "MFMA %", "dgrad us", "HBM %", "wgrad us", "HBM %"))
+tot_f = tot_d = tot_w = 0.0
 for (op, cin, cout, ext, normed, wstats), mods in sorted(seen.items(), key=lambda kv: -kv[0][3][0] * 1000 - kv[0][1]):
     n = 2
     spec = mods[0].spec
@@ -55,11 +55,13 @@ for (op, cin, cout, ext, normed, wstats), mods in sorted(seen.items(), key=lambd
     if y.shape[-1] != cout:
         dy[..., cout:] = 0
     d = timeit(lambda: K.conv(pk.dgrad_op(op), dy, spec.packed(True), None, cin, out=dx, w_ref=w, fwd_op=op))
+    dyv = dy[..., :cout]
+    wg = timeit(lambda: K.wgrad(op, xin, sc if normed else None, sh if normed else None, 0.01, dyv, cout, spec.inv_map, spec.has_bias_map, w.numel()))
     vin, vout = xin.numel() // cin, y.numel() // y.shape[-1]
     byts = 4.0 * (xin.numel() + vout * cout)
     flops = 2.0 * taps[op] * cin * cout * (vout if op != pk.CONVT2 else vout)
     floor = byts / 8e12 * 1e6
     mf = 3 * flops / 2.5e15 * 1e6
-    print("%-8s %4d %4d %-14s %3d | %8.1f %8.1f %6.1f %6.1f | %8.1f %6.1f" % (names[op], cin, cout, "x".join(map(str, ext)), len(mods), f, floor, 100 * floor / f, 100 * mf / f, d, 100 * floor / d), flush=True)
-    tot_f += f * len(mods); tot_d += d * len(mods)
-print("sum over layers: forward %.2f ms, data gradient %.2f ms" % (tot_f / 1e3, tot_d / 1e3))
+    print("%-8s %4d %4d %-14s %3d | %8.1f %8.1f %6.1f %6.1f | %8.1f %6.1f | %8.1f %6.1f" % (names[op], cin, cout, "x".join(map(str, ext)), len(mods), f, floor, 100 * floor / f, 100 * mf / f, d, 100 * floor / d, wg, 100 * floor / wg), flush=True)
+    tot_f += f * len(mods); tot_d += d * len(mods); tot_w += wg * len(mods)
+print("sum over layers: forward %.2f ms, data gradient %.2f ms, weight gradient (slabs + reduce) %.2f ms" % (tot_f / 1e3, tot_d / 1e3, tot_w / 1e3))
