@@ -941,6 +941,169 @@ __global__ __launch_bounds__(256 + 64 * WS1_LW) void wgrad_s1_kernel(const WgArg
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// pw_wgrad: weight gradients of the pointwise family (1x1x1 convs; ConvTranspose k = 2, s = 2), the counterpart of pw_conv_kernel
+// (conv_bf16.hip).  dW[ci][co] = sum_vox xa[vox][ci] * dy[vox][co] is a skinny product over a pure stream -- x and dy are each read
+// once, ~0.5 FLOP per byte -- and the generic 1-tap path above (stage a 256-voxel tile in LDS, barrier, transposed reads, barrier;
+// one launch block per 16-channel chunk, so dy is re-read per chunk) ran it at 10-28 % of the HBM rate (1x1 32->16 @128^3: 366 us
+// for 805 MB with its reduce; tools/layer_table.py).  Here there is no LDS staging and no barrier in the loop:
+//   * v_mfma_f32_16x16x4_f32 contracts FOUR voxels per instruction, one fp32 value per lane: lane (i, k) of the A operand is
+//     x[voxel k][channel i], of the B operand dy[voxel k][channel j] -- exactly what a dword load of 16 consecutive channels x 4
+//     consecutive voxels hands the wave, so fragments come straight from global memory (exact fp32 products: no bf16 rounding);
+//   * a wave owns a contiguous run of 4-voxel groups of ONE sample and ALL (chunk, tile) blocks of the layer: x and dy are read
+//     exactly once; the loads of G groups are issued together (dword loads: 256 B per instruction, so many must be in flight);
+//   * InstanceNorm + activation of x recomputed in registers; bias row = ones operand, as in the tiled kernels;
+//   * the 8 or 16 waves of a workgroup sum their accumulators through LDS: one slab per workgroup (256 in all: the slab reduce
+//     walks the slabs serially per element, 1024 of them cost it 84 us), in the generic slab layout.
+// ---------------------------------------------------------------------------------------------------
+struct PwWgWork { int Vin, gps, wps, gpw; };            // input voxels per sample, 4-voxel groups per sample, workgroups per sample, groups per wave
+
+// waves per workgroup (one workgroup per CU): 16 where the accumulators leave room (<= 128 VGPRs), else 8
+template <int NCH, int NTL, int NCLS> struct PwgCfg { static constexpr int WAVES = (NCLS * NTL * (NCH + 1) <= 12) ? 16 : 8; };
+template <int NCH, int NTL, int NCLS>
+__global__ __launch_bounds__((64 * PwgCfg<NCH, NTL, NCLS>::WAVES)) void pw_wgrad_kernel(const WgArgsB a, const PwWgWork wk, int CG) {
+  constexpr int PWG_WAVES = PwgCfg<NCH, NTL, NCLS>::WAVES, RB = 32 / PWG_WAVES;      // RB: blocks per reduction round
+  constexpr int G = (NCLS > 1) ? (NCH * NTL > 1 ? 1 : 2) : (NCH + NTL <= 2 ? 16 : (NCH + NTL <= 3 ? 12 : (NCH + NTL <= 6 ? 4 : 2)));   // groups per iteration
+  __shared__ float4 red[PWG_WAVES][RB][64];
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = (int)blockIdx.x / wk.wps, wg = (int)blockIdx.x % wk.wps;
+  const int gA = (wg * PWG_WAVES + wave) * wk.gpw;
+  const int gB = min(gA + wk.gpw, wk.gps);
+  const float* xs = a.x + (int64_t)n * wk.Vin * g.x_ldc;
+  const float* ds = a.dy + (int64_t)n * g.Do * g.Ho * g.Wo * a.dy_ldc;
+  const bool has_norm = a.in_scale != nullptr;
+  const bool plain = !has_norm && a.in_slope == 1.f;
+  float sc[NCH], sh[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int ci = c * 16 + li;
+    sc[c] = (has_norm && ci < g.Cin) ? a.in_scale[(int64_t)n * g.Cin + ci] : 1.f;
+    sh[c] = (has_norm && ci < g.Cin) ? a.in_shift[(int64_t)n * g.Cin + ci] : 0.f;
+  }
+  f32x4 acc[NCLS][NCH][NTL], accb[NCLS][NTL];
+#pragma unroll
+  for (int q = 0; q < NCLS; ++q)
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+      accb[q][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) acc[q][c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+  for (int gi = gA; gi < gB; gi += G) {
+    float xv[G][NCH], dv[G][NCLS][NTL];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const bool ok = gi + k < gB;                          // wave-uniform
+      const int vox = (gi + k) * 4 + lk;                    // this lane's voxel of the group
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ci = c * 16 + li;
+        xv[k][c] = (ok && ci < g.Cin) ? xs[(int64_t)vox * g.x_ldc + ci] : 0.f;
+      }
+      int64_t ov[NCLS];
+      if (NCLS == 1) ov[0] = vox;
+      else {
+        const int w_ = vox % g.Wi, t2 = vox / g.Wi, h_ = t2 % g.Hi, d_ = t2 / g.Hi;
+#pragma unroll
+        for (int q = 0; q < NCLS; ++q) ov[q < NCLS ? q : 0] = ((int64_t)(2 * d_ + (q >> 2)) * g.Ho + 2 * h_ + ((q >> 1) & 1)) * g.Wo + 2 * w_ + (q & 1);
+      }
+#pragma unroll
+      for (int q = 0; q < NCLS; ++q)
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+          const int co = t * 16 + li;
+          dv[k][q][t] = (ok && co < g.Cout) ? ds[ov[q] * a.dy_ldc + co] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const bool ok = gi + k < gB;
+      float xa[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        float v = xv[k][c];
+        if (!plain) v = cwf_act(v * sc[c] + sh[c], a.in_slope);
+        xa[c] = (ok && c * 16 + li < g.Cin) ? v : 0.f;      // (a masked lane would otherwise carry act(shift))
+      }
+#pragma unroll
+      for (int q = 0; q < NCLS; ++q)
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+          accb[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, dv[k][q][t], accb[q][t], 0, 0, 0);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) acc[q][c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[c], dv[k][q][t], acc[q][c][t], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- one slab per workgroup: block (class, chunk, group, tap 0 = weights / 1 = bias row, tile) = 64 lanes x float4.
+  // The waves' accumulators meet in LDS RB blocks at a time; waves 0..RB-1 each sum one block over all waves and store it.
+  float4* out = reinterpret_cast<float4*>(a.partial + (int64_t)blockIdx.x * a.slab_floats);
+  constexpr int NB = NCLS * NTL * (NCH + 1);
+  f32x4 flat[NB]; int bid[NB];
+  {
+    int u = 0;
+#pragma unroll
+    for (int q = 0; q < NCLS; ++q)
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        const int grp = t / CG, j = t % CG;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { flat[u] = acc[q][c][t]; bid[u] = a.cls_slab_base[q] + ((c * a.ngroups + grp) * 2) * CG + j; ++u; }
+        // tap slot 1: the all-ones row.  Every chunk's slot is written (the reduce map reads chunk 0's), as in the tiled kernel
+        flat[u] = accb[q][t]; bid[u] = a.cls_slab_base[q] + ((0 * a.ngroups + grp) * 2 + 1) * CG + j; ++u;
+      }
+  }
+#pragma unroll
+  for (int b0 = 0; b0 < NB; b0 += RB) {
+    __syncthreads();
+#pragma unroll
+    for (int r_ = 0; r_ < RB; ++r_)
+      if (b0 + r_ < NB) red[wave][r_][lane] = make_float4(flat[b0 + r_][0], flat[b0 + r_][1], flat[b0 + r_][2], flat[b0 + r_][3]);
+    __syncthreads();
+    if (wave < RB && b0 + wave < NB) {
+      float4 sum = red[0][wave][lane];
+#pragma unroll
+      for (int w = 1; w < PWG_WAVES; ++w) { const float4 p = red[w][wave][lane]; sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w; }
+      int id = bid[b0];
+#pragma unroll
+      for (int r_ = 1; r_ < RB; ++r_) if (b0 + r_ < NB && wave == r_) id = bid[b0 + r_];
+      out[(int64_t)id * 64 + lane] = sum;
+      if (NCH > 1) {                                        // the bias rows of chunks 1.. (same values)
+#pragma unroll
+        for (int r_ = 0; r_ < RB; ++r_) {
+          if (b0 + r_ < NB && wave == r_ && (b0 + r_) % (NCH + 1) == NCH) {
+            for (int c = 1; c < NCH; ++c) out[((int64_t)id + (int64_t)c * a.ngroups * 2 * CG) * 64 + lane] = sum;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int NCH, int NTL, int NCLS>
+static int launch_pw_wgrad(const WgArgsB& a, int CG, int max_slabs, int* nsplit_used, hipStream_t st) {
+  const ConvGeom& g = a.g;
+  PwWgWork wk;
+  wk.Vin = g.Di * g.Hi * g.Wi;
+  wk.gps = wk.Vin >> 2;
+  int wps = 256 / g.N; if (wps < 1) wps = 1;               // ~256 eight-wave workgroups in all (one per CU), each inside one sample
+  if (wps * g.N > max_slabs) wps = max_slabs / g.N;
+  if (wps < 1) return -1;
+  constexpr int PWG_WAVES = PwgCfg<NCH, NTL, NCLS>::WAVES;
+  const int maxw = cdiv(wk.gps, PWG_WAVES * 8);
+  if (wps > maxw) wps = maxw;
+  wk.gpw = cdiv(wk.gps, wps * PWG_WAVES);
+  wk.wps = cdiv(wk.gps, wk.gpw * PWG_WAVES);
+  hipLaunchKernelGGL((pw_wgrad_kernel<NCH, NTL, NCLS>), dim3((unsigned)(wk.wps * g.N)), dim3(64 * PWG_WAVES), 0, st, a, wk, CG);
+  CWF_LAUNCH_CHECK();
+  if (nsplit_used) *nsplit_used = wk.wps * g.N;
+  return 0;
+}
+
 // plan: identical decisions to wgrad_mfma.hip (the Python side sizes the workspace through cwf_wgrad_nsplit / _slab_floats)
 extern "C" int cwf_wgrad_nsplit(int op, int N, int Do, int Ho, int Wo, int Cin, int Cout);
 extern "C" int64_t cwf_wgrad_slab_floats(int op, int Cin, int Cout);
@@ -989,6 +1152,27 @@ extern "C" int cwf_wgrad_mfma_bf16(int op, int x3, const float* x, int x_ldc, co
     CWF_LAUNCH_CHECK();
     if (nsplit_used) *nsplit_used = grid;
     return 0;
+  }
+  if ((op == CWF_CONV1 || op == CWF_CONVT2) && ((int64_t)Di * Hi * Wi & 3) == 0 && (op == CWF_CONV1 || (Wi & 3) == 0) &&
+      (int64_t)Di * Hi * Wi * (x_ldc > 8 * dy_ldc ? x_ldc : 8 * dy_ldc) < (1ll << 31)) {
+    // pointwise layers: stream kernel (fp32 MFMA straight from global memory, every operand read once), both precision modes
+    static const bool off = getenv("CWF_NO_PW_WGRAD") != nullptr;        // A/B switch (diagnostics)
+    const int nch = nchunks, ntl = a.g.ntiles;
+    const int max_slabs = wg_splits * 4;                  // what the workspace was sized for
+    hipStream_t stp = cwf_stream(stream);
+    int r = -2;
+    if (!off) {
+      if (op == CWF_CONV1) {
+        if (nch == 1 && ntl == 1) r = launch_pw_wgrad<1, 1, 1>(a, CG, max_slabs, nsplit_used, stp);
+        else if (nch == 2 && ntl == 1) r = launch_pw_wgrad<2, 1, 1>(a, CG, max_slabs, nsplit_used, stp);
+        else if (nch == 4 && ntl == 2) r = launch_pw_wgrad<4, 2, 1>(a, CG, max_slabs, nsplit_used, stp);
+        else if (nch == 8 && ntl == 4) r = launch_pw_wgrad<8, 4, 1>(a, CG, max_slabs, nsplit_used, stp);
+      } else {
+        if (nch == 1 && ntl == 1) r = launch_pw_wgrad<1, 1, 8>(a, CG, max_slabs, nsplit_used, stp);
+        else if (nch == 2 && ntl == 2) r = launch_pw_wgrad<2, 2, 8>(a, CG, max_slabs, nsplit_used, stp);
+      }
+    }
+    if (r >= 0) return r;
   }
   if (!x3 && op == CWF_CONV3_S1 && CG <= 2 && a.g.TD == 4 && a.g.TH == 4 && a.g.ID == 6 && a.g.IH == 6 && a.g.IW == 18 && (Cout & 3) == 0 &&
       (dy_ldc & 3) == 0 && (((uintptr_t)dy) & 15) == 0) {

@@ -243,6 +243,43 @@ def test_parity_class_outputs_take_the_fast_epilogue(hip, prec):
     close(st, st_ref, rtol=max(1e-5, tol), what="convT stats")
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("op,cin,cout,size,n", [
+    (pk.CONV1, 32, 16, (8, 8, 32), 2),
+    (pk.CONV1, 16, 4, (4, 6, 10), 3),            # 240 voxels per sample: ragged runs of 4-voxel groups
+    (pk.CONV1, 64, 32, (8, 8, 16), 1),
+    (pk.CONV1, 128, 64, (4, 4, 8), 2),
+    (pk.CONV1, 20, 12, (4, 4, 16), 2),           # partial channel blocks
+    (pk.CONVT2, 16, 16, (4, 6, 8), 2),
+    (pk.CONVT2, 32, 32, (4, 4, 12), 1),
+])
+def test_pointwise_weight_gradient_stream(hip, op, cin, cout, size, n, prec):
+    """pw_wgrad_kernel (wgrad_bf16.hip): weight / bias gradients of the 1x1x1 and transposed layers from fp32 MFMA fragments loaded
+    straight from global memory, with the recomputed InstanceNorm + activation prologue; against the oracle emulation at the fp32
+    tolerance in BOTH precision modes (the products are exact fp32)."""
+    from cwf import functional as CF
+    d, h, w_ = size
+    x = rnd(n, d, h, w_, cin, seed=51)
+    wshape = (cin, cout, 2, 2, 2) if op == pk.CONVT2 else (cout, cin, 1, 1, 1)
+    w = rnd(*wshape, seed=52, scale=1.0 / math.sqrt(cin))
+    spec = _packed(CF.ConvSpec(op, cin, cout), w, prec)
+    do, ho, wo = pk.out_dims(op, d, h, w_)
+    dy = rnd(n, do, ho, wo, cout, seed=58)
+    in_scale, in_shift = rnd(n, cin, seed=54).abs() + 0.5, rnd(n, cin, seed=55)
+    for sc, sh, slope in ((in_scale, in_shift, 0.01), (None, None, 1.0)):
+        gw_ref, gb_ref = E.wgrad(op, x, sc, sh, slope, dy, cout, None, spec.has_bias_map, w.numel(), w_ref_shape=w.shape)
+        gw, gb = hip.wgrad(op, x.to(DEV), None if sc is None else sc.to(DEV), None if sh is None else sh.to(DEV), slope, dy.to(DEV), cout,
+                           spec.inv_map, spec.has_bias_map, w.numel(), prec=prec)
+        close(gw, gw_ref, rtol=5e-5, what="wgrad")
+        if gb is not None:
+            close(gb, gb_ref, rtol=5e-5, what="bgrad")
+    # strided operands: x and dy as channel slices of wider buffers (concatenation buffer / padded gradient)
+    xw = torch.zeros((n, d, h, w_, cin + 4), device=DEV); xw[..., :cin] = x.to(DEV)
+    dw = torch.zeros((n, do, ho, wo, cout + 8), device=DEV); dw[..., 4:4 + cout] = dy.to(DEV)
+    gw2, _ = hip.wgrad(op, xw[..., :cin], None, None, 1.0, dw[..., 4:4 + cout], cout, spec.inv_map, spec.has_bias_map, w.numel(), prec=prec)
+    close(gw2, gw_ref, rtol=5e-5, what="wgrad strided")
+
+
 def test_gather_batched_matches_index_maps(hip):
     from cwf import functional as CF
     packer = CF.WeightPacker()
