@@ -59,13 +59,20 @@ def usable_cores():
 TRAFFIC_FILE = os.path.join(REPO, "profiles", "dominant_kernel_traffic.json")
 
 
-def measured_traffic(precision):
+def conv16s_source_sha():
+    """sha256 (16 hex digits) of the dominant kernel's own source region in conv_bf16.hip (from its header comment to the end of its
+    launcher): the committed PMC record stays valid while THAT text is unchanged, whatever else the file gains."""
     import hashlib
+    src = open(os.path.join(PKG, "csrc", "conv_bf16.hip"), "rb").read()
+    a, b = src.find(b"// conv16s: conv16 with a SLIDING WINDOW"), src.find(b"// Pointwise family")
+    return hashlib.sha256(src[a:b] if 0 <= a < b else src).hexdigest()[:16]
+
+
+def measured_traffic(precision):
     try:
         rec = json.load(open(TRAFFIC_FILE))[precision]
-        src = open(os.path.join(PKG, "csrc", "conv_bf16.hip"), "rb").read()
-        if rec.get("conv_bf16_sha16") != hashlib.sha256(src).hexdigest()[:16]:
-            return None, "stale: %s was measured on another build of conv_bf16.hip" % rec.get("source")
+        if rec.get("conv16s_sha16") != conv16s_source_sha():
+            return None, "stale: %s was measured on another build of conv16s_kernel" % rec.get("source")
         return float(rec["hbm_bytes_per_launch"]), rec.get("source")
     except Exception as e:          # missing file / precision: report null rather than a guess
         return None, "no committed PMC summary (%s)" % type(e).__name__
