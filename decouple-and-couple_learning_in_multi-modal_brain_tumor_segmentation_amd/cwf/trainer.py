@@ -75,7 +75,12 @@ class Trainer:
         self._eager_steps = 0
         self._graph_warmup = graph_warmup
         self._in_backward = False
-        self.defer_decoder_wgrad = os.environ.get("CWF_DEFER_WGRAD", "0") == "1"      # experiment switch (no measurable effect: DESIGN.md section 4)
+        # The decoder's (full-resolution) weight gradients are queued and released when backward leaves the decoder: they then run
+        # beside the backward of the supervision heads / couplers -- 10-20 us kernels behind ~35 us of Python each, where the main
+        # stream idles 1.7 ms per step -- instead of competing with the decoder's own HBM-bound data gradients (95.6 -> 96.7
+        # volumes/s; neutral while the step was still bound elsewhere).  CWF_DEFER_WGRAD=0 launches them immediately.
+        self.defer_level = int(os.environ.get("CWF_DEFER_WGRAD", "1"))
+        self.defer_decoder_wgrad = self.defer_level >= 1
 
     # ------------------------------------------------------------------------------------------------
     def _phase_done(self, k):
@@ -85,8 +90,12 @@ class Trainer:
         if not self._in_backward:
             return
         K = kernels_backend()
-        if k == 0 and getattr(K, "wgrad_defer", False):
-            K.wgrad_release()          # the decoder's weight gradients start now, beside the GPU-light heads / couplers backward
+        if getattr(K, "wgrad_defer", False):
+            # the weight gradients queued during the phase that just ended start now.  Decoder (k = 0): beside the GPU-light heads /
+            # couplers backward.  Heads / couplers / decouplers (k = 1, level 2): their ~40 small side-stream launches leave the
+            # host-bound stretch and are enqueued where the host has slack (the encoder's backward).  The last phase is never held.
+            K.wgrad_release()
+            K.wgrad_defer = self.wgrad_async and self.defer_level >= 2 and k == 0
         K.wgrad_flush()
         if self.overlap_comm and not _capturing():
             self._allreduce_chunk(k)
