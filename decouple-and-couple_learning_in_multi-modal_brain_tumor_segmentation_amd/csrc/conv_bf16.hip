@@ -53,15 +53,23 @@ struct StageSlots { int goff[CB_MAXS]; unsigned inb; int nslots; };
 __device__ __forceinline__ void stage_slots_init(StageSlots& ss, const ConvGeom& g, int id0, int ih0, int iw0, int tid) {
   const int nvox_in = g.ID * g.IH * g.IW;
   ss.nslots = (nvox_in + 63) >> 6; ss.inb = 0u;
+  // (idd, ih, iw) of slot i's voxel v = (tid >> 2) + 64 i, INCREMENTALLY: two integer divisions for slot 0, then adds and carries
+  // (64 = dq * IW + dr).  Thirteen slots x two runtime divisions per thread was ~1000 VALU instructions per workgroup -- a third of
+  // the stride-2 forward launches, whose workgroups own a single 64-voxel tile (16 -> 32 @128^3: 209 us).
+  const int dq = 64 / g.IW, dr = 64 - dq * g.IW;          // wave-uniform
+  int iw = (tid >> 2) % g.IW, t2 = (tid >> 2) / g.IW;
+  int ih = t2 % g.IH, idd = t2 / g.IH;
 #pragma unroll
   for (int i = 0; i < CB_MAXS; ++i) {
     const int v = (tid >> 2) + 64 * i;
-    const int iw = v % g.IW; const int t2 = v / g.IW;
-    const int ih = t2 % g.IH; const int idd = t2 / g.IH;
     const int gd = id0 + idd, gh = ih0 + ih, gw = iw0 + iw;
     const bool ok = v < nvox_in && gd >= 0 && gd < g.Di && gh >= 0 && gh < g.Hi && gw >= 0 && gw < g.Wi;
     ss.goff[i] = ok ? ((gd * g.Hi + gh) * g.Wi + gw) * g.x_ldc : 0;
     ss.inb |= ok ? (1u << i) : 0u;
+    iw += dr; int adv = dq;
+    if (iw >= g.IW) { iw -= g.IW; ++adv; }
+    ih += adv;
+    while (ih >= g.IH) { ih -= g.IH; ++idd; }              // (adv <= 64 / IW + 1: a few rows at most)
   }
 }
 
