@@ -26,6 +26,11 @@ struct ConvArgsB {
   // stats receives per (n, channel)  S1 = sum g*act'(h), S2 = sum g*act'(h)*h,  h = nb_x*nb_scale + nb_shift  -- what
   // cwf_in_bwd_stats would compute in a separate pass over g and x (norm.hip) -- instead of (sum y, sum y^2).
   const float* nb_x; int nb_ldc; const float* nb_scale; const float* nb_shift; float nb_slope;
+  // channel-grouped launches (cwf_conv_mfma_bf16_grouped: the three sub-regions' supervision-head convs as one launch): group q reads
+  // input channels [q*x_goff, q*x_goff + Cin) and writes output channels [q*y_goff, q*y_goff + Cout) of the same voxel rows, with its
+  // own packed weights and bias; blockIdx.z = (group * N + n) * ncls + class.  groups == 0: an ordinary launch.
+  int groups, x_goff, y_goff;
+  const uint4* wpk_g[3]; const float* bias_g[3];
 };
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -141,7 +146,12 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
   const int tile_w = bx % g.tiles_w; bx /= g.tiles_w;
   const int tile_h = bx % g.tiles_h;
   const int tile_d = bx / g.tiles_h;
-  const int n = blockIdx.z / g.ncls, cls = blockIdx.z % g.ncls;
+  const int zq = blockIdx.z / g.ncls, cls = blockIdx.z % g.ncls;
+  const int grp = a.groups ? zq / g.N : 0, n = a.groups ? zq % g.N : zq;
+  const float* a_x = a.x + grp * a.x_goff;               // (workgroup-uniform: group operands)
+  float* a_y = a.y + grp * a.y_goff;
+  const uint4* a_wpk = a.groups ? a.wpk_g[grp] : a.wpk;
+  const float* a_bias = a.groups ? a.bias_g[grp] : a.bias;
   const int Dc = g.cls_dims[cls][0], Hc = g.cls_dims[cls][1], Wc = g.cls_dims[cls][2];
   const int od0 = tile_d * g.TD, oh0 = tile_h * g.TH, ow0 = tile_w * 16;
   if (od0 >= Dc || oh0 >= Hc || ow0 >= Wc) return;
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
   constexpr int PD = MT == 1 ? (NT <= 2 ? 4 : 2) : 1;   // large-MT configurations: one step ahead (deeper rings cost them an occupancy step)
   for (int chunk = 0; chunk < g.nchunks; ++chunk) {
     // packed weights: block = 64 lanes x (hi 16 B | lo 16 B) = 128 uint4
-    const uint4* wchunk = a.wpk + ((int64_t)g.cls_wbase16[cls] + (int64_t)chunk * nsteps * g.ntiles) * 128 + lane * 2;
+    const uint4* wchunk = a_wpk + ((int64_t)g.cls_wbase16[cls] + (int64_t)chunk * nsteps * g.ntiles) * 128 + lane * 2;
     uint4 bh[PD][NT], bl[PD][NT];
     // unconditional loads (indices clamped into the packed buffer: a partial channel group or a step past the end re-reads
     // valid data that is never used) -- a branch around a global load makes the compiler give up counted s_waitcnt vmcnt(N),
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
 #pragma unroll
     for (int d = 0; d < PD; ++d) load_b(d, d);
     if (chunk) __syncthreads();
-    stage_tile_bf16<X3>(xh, xl, g, a.x, a.in_scale, a.in_shift, a.in_slope, n, chunk, ss, tid);
+    stage_tile_bf16<X3>(xh, xl, g, a_x, a.in_scale, a.in_shift, a.in_slope, n, chunk, ss, tid);
     __syncthreads();
     auto step = [&](int s, int d, bool refill) {          // tap pair s with ring slot d
       const int t0 = tapofs[2 * s];
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int co = (nt0 + j) * 16 + r;
-      bvj[j] = a.bias ? a.bias[co] : 0.f;
+      bvj[j] = a_bias ? a_bias[co] : 0.f;
       if (a.out_scale) {
         const float osc = a.out_scale[(int64_t)n * g.Cout + co];
 #pragma unroll
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
         const int mt = wm * MT + m;
         const int od = od0 + mt / g.TH, oh = oh0 + mt % g.TH;
         const int64_t vox0 = (((int64_t)n * g.Do + od * os + of0) * g.Ho + oh * os + of1) * g.Wo + ow0 * os + of2;
-        char* yb = reinterpret_cast<char*>(a.y + vox0 * g.y_ldc);
+        char* yb = reinterpret_cast<char*>(a_y + vox0 * g.y_ldc);
         const char* rb = HAS_RES ? reinterpret_cast<const char*>(a.residual + vox0 * a.r_ldc) : nullptr;
         const char* xb = HAS_NB ? reinterpret_cast<const char*>(a.nb_x + vox0 * a.nb_ldc) : nullptr;
         float rv[NT][4], xv[NT][4];
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
   for (int j = 0; j < NT; ++j) {
     const int co = (nt0 + j) * 16 + r;
     if (co >= g.Cout) continue;
-    const float bv = a.bias ? a.bias[co] : 0.f;
+    const float bv = a_bias ? a_bias[co] : 0.f;
     const float osc = a.out_scale ? a.out_scale[(int64_t)n * g.Cout + co] : 1.f;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvArgsB a) {
         float v = acc[m][j][i] + bv;
         if (a.residual) v += a.residual[vox * a.r_ldc + co];
         v *= osc;
-        a.y[vox * g.y_ldc + co] = v;
+        a_y[vox * g.y_ldc + co] = v;
         if (a.nb_x) {
           const float h = fmaf(a.nb_x[vox * a.nb_ldc + co], a.nb_scale[(int64_t)n * g.Cout + co], a.nb_shift[(int64_t)n * g.Cout + co]);
           const float gn = v * (h > 0.f ? 1.f : a.nb_slope);
@@ -1630,7 +1640,7 @@ int launch_cfg(const ConvArgsB& a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MT, NT, WM, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  dim3 grid(g.tiles_d * g.tiles_h * g.tiles_w, cdiv(g.ntiles, WN * NT), g.N * g.ncls);
+  dim3 grid(g.tiles_d * g.tiles_h * g.tiles_w, cdiv(g.ntiles, WN * NT), g.N * g.ncls * (a.groups ? a.groups : 1));
   hipLaunchKernelGGL((conv_bf16_kernel<MT, NT, WM, X3>), grid, dim3(256), lds, st, a);
   CWF_LAUNCH_CHECK();
   return 0;
@@ -1677,6 +1687,8 @@ extern "C" int cwf_conv_mfma_bf16_nb(int op, int x3, const float* x, int x_ldc, 
   a.in_slope = in_slope; a.residual = residual; a.r_ldc = r_ldc; a.out_scale = out_scale; a.stats = stats;
   a.nb_x = nb_x; a.nb_ldc = nb_ldc; a.nb_scale = nb_scale; a.nb_shift = nb_shift; a.nb_slope = nb_slope;
   a.diag = nullptr; a.diag_mode = 0;
+  a.groups = 0; a.x_goff = 0; a.y_goff = 0;
+  for (int q = 0; q < 3; ++q) { a.wpk_g[q] = nullptr; a.bias_g[q] = nullptr; }
   hipStream_t st = cwf_stream(stream);
   {
     int ks, nt;
@@ -1698,6 +1710,45 @@ extern "C" int cwf_conv_mfma_bf16_nb(int op, int x3, const float* x, int x_ldc, 
     if ((!noslide && !g_conv16_diag) || nb_x) return x3 ? launch_conv16s<true>(a, st) : launch_conv16s<false>(a, st);   // (conv16 has no nb epilogue)
     return x3 ? launch_conv16<true>(a, st) : launch_conv16<false>(a, st);
   }
+#define CWF_CFG(mt, nt, wm) if (c.MT == mt && c.NT == nt && c.WM == wm) return x3 ? launch_cfg<mt, nt, wm, true>(a, st) : launch_cfg<mt, nt, wm, false>(a, st);
+  CWF_CFG(4, 4, 1) CWF_CFG(2, 4, 2) CWF_CFG(2, 4, 4) CWF_CFG(4, 2, 4) CWF_CFG(4, 1, 4)
+  CWF_CFG(1, 4, 4) CWF_CFG(1, 2, 4) CWF_CFG(1, 2, 2) CWF_CFG(1, 1, 4)
+#undef CWF_CFG
+  return CWF_E_BADARG;
+}
+
+// Channel-grouped 3x3x3 stride-1 conv (forward, or data gradient through transposed packed weights): `groups` (2 or 3) independent
+// convs Cin -> Cout on channel groups of one input tensor, written into channel groups of one output tensor, ONE launch (the
+// supervision heads of the three sub-regions: SuperviseLabel.py:58-81, EdgeSuperviseLabel.py:56-76 -- 24 tiny layers per step whose
+// launches, not their arithmetic, are the cost).  Bias only: no normalising prologue, residual, out_scale or statistics.
+extern "C" int cwf_conv_mfma_bf16_grouped(int op, int x3, const float* x, int x_ldc, int x_goff, const void* const* wpk16, const float* const* bias,
+                                          float* y, int y_ldc, int y_goff, int groups,
+                                          int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, void* stream) {
+  if (!x || !wpk16 || !y || N <= 0 || Cin <= 0 || Cout <= 0 || groups < 2 || groups > 3) return CWF_E_BADARG;
+  if (op != CWF_CONV3_S1) return CWF_E_BADARG;
+  if ((Cin & 3) || (x_ldc & 3) || (x_goff & 3) || x_ldc < (groups - 1) * x_goff + Cin || y_ldc < (groups - 1) * y_goff + Cout) return CWF_E_ALIGN;
+  if ((uintptr_t)x & 15) return CWF_E_ALIGN;
+  ConvArgsB a;
+  int cd[3] = {Do, Ho, Wo};
+  TileCfg c = choose_cfg(op, cd, 1, N * groups, cdiv(Cout, 16));
+  int rc = cwf_build_geom(a.g, op, N, Di, Hi, Wi, Cin, x_ldc, Do, Ho, Wo, Cout, y_ldc, c.MT * c.WM);
+  if (rc) return rc;
+  a.x = x; a.wpk = nullptr; a.bias = nullptr; a.y = y; a.in_scale = nullptr; a.in_shift = nullptr; a.in_slope = 1.f;
+  a.residual = nullptr; a.r_ldc = 0; a.out_scale = nullptr; a.stats = nullptr;
+  a.nb_x = nullptr; a.nb_ldc = 0; a.nb_scale = nullptr; a.nb_shift = nullptr; a.nb_slope = 1.f;
+  a.diag = nullptr; a.diag_mode = 0;
+  a.groups = groups; a.x_goff = x_goff; a.y_goff = y_goff;
+  for (int q = 0; q < 3; ++q) {
+    a.wpk_g[q] = q < groups ? reinterpret_cast<const uint4*>(wpk16[q]) : nullptr;
+    a.bias_g[q] = (q < groups && bias) ? bias[q] : nullptr;
+    if (q < groups && (!wpk16[q] || ((uintptr_t)wpk16[q] & 15))) return CWF_E_ALIGN;
+  }
+  if (Cin <= 16 && Cout <= 16) {                           // these layers are packed in conv16's tap order (c16_tap)
+    int nat[27];
+    for (int t = 0; t < 27; ++t) nat[t] = a.g.tapofs[t];
+    for (int t = 0; t < 27; ++t) a.g.tapofs[t] = nat[c16_tap(t)];
+  }
+  hipStream_t st = cwf_stream(stream);
 #define CWF_CFG(mt, nt, wm) if (c.MT == mt && c.NT == nt && c.WM == wm) return x3 ? launch_cfg<mt, nt, wm, true>(a, st) : launch_cfg<mt, nt, wm, false>(a, st);
   CWF_CFG(4, 4, 1) CWF_CFG(2, 4, 2) CWF_CFG(2, 4, 4) CWF_CFG(4, 2, 4) CWF_CFG(4, 1, 4)
   CWF_CFG(1, 4, 4) CWF_CFG(1, 2, 4) CWF_CFG(1, 2, 2) CWF_CFG(1, 1, 4)

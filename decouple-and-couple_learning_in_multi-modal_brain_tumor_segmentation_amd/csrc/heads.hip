@@ -387,14 +387,16 @@ __global__ void head_loss_bwd_rows_kernel(const HeadLossArgs a) {
   }
 }
 
-struct HeadPlanesArgs { float* dlogit[3]; const float* ws; int dl_ldc, N, D, H, W, scale, nm; int64_t per_map; };
-// dlogit_m[n][jd][jh][jw][c] = sum_od fd(od, jd) ws[m][n][od][jh][jw][c] for c < 2, ZERO for the pad channels c in [2, dl_ldc)
+struct HeadPlanesArgs { float* dlogit[3]; const float* ws; int dl_ldc, dl_ca, N, D, H, W, scale, nm; int64_t per_map; };
+// dlogit_m[n][jd][jh][jw][c] = sum_od fd(od, jd) ws[m][n][od][jh][jw][c] for c < 2, ZERO for the pad channels c in [2, dl_ca);
+// voxel rows are dl_ldc floats apart (dl_ldc > dl_ca: the maps are channel groups of one gradient buffer, cwf_head_loss_bwd_ex)
 __global__ void head_loss_bwd_planes_kernel(const HeadPlanesArgs a) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // over (n, jd, jh, jw, c < dl_ldc)
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // over (n, jd, jh, jw, c < dl_ca)
   if (idx >= a.per_map) return;
   const int m = blockIdx.y;
   int64_t v = idx;
-  const int c = (int)(v % a.dl_ldc); v /= a.dl_ldc;
+  const int c = (int)(v % a.dl_ca); v /= a.dl_ca;
+  const int64_t vox = v;
   const int64_t hw = v % ((int64_t)a.H * a.W); v /= (int64_t)a.H * a.W;
   const int jd = (int)(v % a.D); const int n = (int)(v / a.D);
   float s = 0.f;
@@ -405,7 +407,7 @@ __global__ void head_loss_bwd_planes_kernel(const HeadPlanesArgs a) {
     for (int od = od_lo; od < od_hi; ++od)
       s += tri_weight(od, inv, a.D, jd) * a.ws[(((((int64_t)m * a.N + n) * Do + od) * a.H * a.W) + hw) * 2 + c];
   }
-  a.dlogit[m][idx] = s;
+  a.dlogit[m][vox * a.dl_ldc + c] = s;
 }
 
 extern "C" int cwf_head_loss_sums(const float* const* logits, int nmaps, int l_ldc, const uint32_t* posmasks, const int64_t* label,
@@ -422,11 +424,19 @@ extern "C" int cwf_head_loss_sums(const float* const* logits, int nmaps, int l_l
   return 0;
 }
 
+extern "C" int cwf_head_loss_bwd_ex(const float* const* logits, int nmaps, int l_ldc, const uint32_t* posmasks, const int64_t* label,
+                                    const float* coef, const float* gscale, float* const* dlogits, int dl_ca, int dl_ldc, float* workspace,
+                                    int N, int D, int H, int W, int scale, void* stream);
 extern "C" int cwf_head_loss_bwd(const float* const* logits, int nmaps, int l_ldc, const uint32_t* posmasks, const int64_t* label,
                                  const float* coef, const float* gscale, float* const* dlogits, int dl_ldc, float* workspace,
                                  int N, int D, int H, int W, int scale, void* stream) {
+  return cwf_head_loss_bwd_ex(logits, nmaps, l_ldc, posmasks, label, coef, gscale, dlogits, dl_ldc, dl_ldc, workspace, N, D, H, W, scale, stream);
+}
+extern "C" int cwf_head_loss_bwd_ex(const float* const* logits, int nmaps, int l_ldc, const uint32_t* posmasks, const int64_t* label,
+                                    const float* coef, const float* gscale, float* const* dlogits, int dl_ca, int dl_ldc, float* workspace,
+                                    int N, int D, int H, int W, int scale, void* stream) {
   if (!logits || !posmasks || !label || !coef || !gscale || !dlogits || !workspace || nmaps <= 0 || nmaps > 3 || N <= 0) return CWF_E_BADARG;
-  if (scale <= 0 || (scale & 1) || l_ldc < 2 || dl_ldc < 2) return CWF_E_BADARG;
+  if (scale <= 0 || (scale & 1) || l_ldc < 2 || dl_ca < 2 || dl_ldc < dl_ca) return CWF_E_BADARG;
   HeadLossArgs a = {};
   HeadPlanesArgs pa = {};
   for (int m = 0; m < nmaps; ++m) {
@@ -441,8 +451,8 @@ extern "C" int cwf_head_loss_bwd(const float* const* logits, int nmaps, int l_ld
   if (lds > 64 * 1024) return CWF_E_BADARG;
   hipStream_t st = cwf_stream(stream);
   hipLaunchKernelGGL(head_loss_bwd_rows_kernel, dim3((unsigned)((int64_t)N * D * scale * H)), dim3(threads), lds, st, a);
-  pa.ws = workspace; pa.dl_ldc = dl_ldc; pa.N = N; pa.D = D; pa.H = H; pa.W = W; pa.scale = scale; pa.nm = nmaps;
-  pa.per_map = (int64_t)N * D * H * W * dl_ldc;
+  pa.ws = workspace; pa.dl_ldc = dl_ldc; pa.dl_ca = dl_ca; pa.N = N; pa.D = D; pa.H = H; pa.W = W; pa.scale = scale; pa.nm = nmaps;
+  pa.per_map = (int64_t)N * D * H * W * dl_ca;
   hipLaunchKernelGGL(head_loss_bwd_planes_kernel, dim3((unsigned)cdiv64(pa.per_map, 256), nmaps), dim3(256), 0, st, pa);
   CWF_LAUNCH_CHECK();
   return 0;

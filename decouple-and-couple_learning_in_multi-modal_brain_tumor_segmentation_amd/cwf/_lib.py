@@ -84,6 +84,8 @@ SIGNATURES = {
     "cwf_dice_ce_finalize_multi": [P, P, P, P, I, I, L, I, P],
     "cwf_head_loss_sums": [P, I, I, P, P, P, I, I, I, I, I, P],
     "cwf_head_loss_bwd": [P, I, I, P, P, P, P, P, I, P, I, I, I, I, I, P],
+    "cwf_head_loss_bwd_ex": [P, I, I, P, P, P, P, P, I, I, P, I, I, I, I, I, P],
+    "cwf_conv_mfma_bf16_grouped": [I, I, P, I, I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
     "cwf_ln_pair_fwd_g": [P, P, I, P, I, P, P, P, I, I, F, P],
     "cwf_ln_pair_bwd_g": [P, P, P, P, P, I, P, I, P, P, P, I, I, I, P],
     "cwf_token_scores2_g": [P, P, P, I, I, P, P, I, I, I, P],

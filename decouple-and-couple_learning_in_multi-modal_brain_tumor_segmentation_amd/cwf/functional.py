@@ -330,6 +330,76 @@ def conv(x, w, b, spec, in_norm=None, slope=1.0, residual=None, out_scale=None, 
     return (y, st, xc) if carry else (y, st)
 
 
+class _GroupedConvFn(torch.autograd.Function):
+    """G same-shape 3x3x3 stride-1 convs on the channel groups of ONE tensor, one launch each way:
+        y_all[..., q*Ca : q*Ca + Cout] = conv_q(x_all[..., q*Cin : (q+1)*Cin]) + b_q          (Ca = Cout rounded up to 4)
+    (the three sub-regions' supervision-head layers: 24 tiny convs per step whose launches, not their arithmetic, are the cost).
+    Weight gradients stay per layer (their slabs go to the layer's own slice of the flat gradient buffer)."""
+
+    @staticmethod
+    def forward(ctx, x_all, specs, *wb):
+        K = backend()
+        G = len(specs)
+        s0 = specs[0]
+        if s0.dev is not None and x_all.device != s0.dev:
+            raise RuntimeError("grouped conv: packed weights live on %s but the input is on %s (one process per GPU)" % (s0.dev, x_all.device))
+        n, d, h, w, _ = x_all.shape
+        ca = s0.cout_alloc or s0.cout
+        for s_ in specs:
+            s_.uses += 1
+        y_all = torch.empty((n, d, h, w, G * ca), dtype=torch.float32, device=x_all.device)
+        K.conv_grouped(x_all, s0.cin, [s_.packed(False) for s_ in specs], [wb[2 * q + 1] for q in range(G)], s0.cout, y_all,
+                       x_goff=s0.cin, y_goff=ca, w_refs=[wb[2 * q] for q in range(G)])
+        ctx.specs = specs
+        ctx.save_for_backward(x_all, *wb)
+        return y_all
+
+    @staticmethod
+    def backward(ctx, dy_all):
+        K = backend()
+        x_all, *wb = ctx.saved_tensors
+        specs = ctx.specs
+        G = len(specs)
+        s0 = specs[0]
+        cin, cout = s0.cin, s0.cout
+        ca = s0.cout_alloc or cout
+        dy_all = dy_all.contiguous()
+        sink = active_sink()
+        grads = []
+        for q, spec in enumerate(specs):
+            w, b = wb[2 * q], wb[2 * q + 1]
+            xs = x_all[..., q * cin:(q + 1) * cin]
+            dys = dy_all[..., q * ca:q * ca + cout]
+            sw = sink.view(w) if (sink is not None and spec.uses <= 1 and ctx.needs_input_grad[2 + 2 * q]) else None
+            sb = sink.view(b) if (sw is not None and b is not None) else None
+            if sw is not None and (b is None or sb is not None):
+                K.wgrad_to(spec, spec.op, xs, None, None, 1.0, dys, cout, spec.inv_map, sw, sb if spec.has_bias_map else None, allow_async=True)
+                sink.mark(w)
+                if sb is not None:
+                    sink.mark(b)
+                grads += [None, None]
+            elif ctx.needs_input_grad[2 + 2 * q]:
+                dwf, db = K.wgrad(spec.op, xs, None, None, 1.0, dys, cout, spec.inv_map, spec.has_bias_map, w.numel(), w_ref_shape=w.shape,
+                                  allow_async=spec.uses <= 1 and w.grad is None)
+                grads += [dwf.view(w.shape), db]
+            else:
+                grads += [None, None]
+        dx_all = None
+        if ctx.needs_input_grad[0]:
+            dx_all = torch.empty(x_all.shape, dtype=torch.float32, device=x_all.device)
+            K.conv_grouped(dy_all, ca, [s_.packed(True) for s_ in specs], None, cin, dx_all, x_goff=ca, y_goff=cin,
+                           w_refs=[wb[2 * q] for q in range(G)], fwd_op=pk.CONV3_S1)
+        return (dx_all, None) + tuple(grads)
+
+
+def grouped_conv(x_all, mods):
+    """mods: G HipConv-like modules (weight, bias, spec) of one shape, 3x3x3 stride 1; x_all [N,d,h,w,G*Cin] -> [N,d,h,w,G*Ca]."""
+    flat = []
+    for m in mods:
+        flat += [m.weight, m.bias]
+    return _GroupedConvFn.apply(x_all, tuple(m.spec for m in mods), *flat)
+
+
 class NaaLink:
     """Connects a block tail y = act(IN(g)) + x (norm_act_add) with the ONE conv that consumes y: that conv's data gradient
     produces dL/dy, and its epilogue can accumulate the two InstanceNorm-backward sums of the tail (sum dy act', sum dy act' ghat)
@@ -713,8 +783,9 @@ class LazyProb:
     a torch function, a tensor method -- materialises the real map through the ordinary upsample_softmax Function (same values,
     autograd intact), so code written against the reference's tensors keeps working."""
 
-    def __init__(self, logit, c, scale):
+    def __init__(self, logit, c, scale, parent=None):
         self.logit, self.c, self.scale = logit, c, scale
+        self.parent = parent                       # (grouped logit buffer [N,d,h,w,G*ca], group index, G, ca): head_group_loss
         self._t = None
 
     def materialize(self):
@@ -762,11 +833,38 @@ class _HeadGroupLossFn(torch.autograd.Function):
         return (None, None, None) + tuple(dls)
 
 
+class _HeadGroupLossGFn(torch.autograd.Function):
+    """_HeadGroupLossFn for maps whose logits are the channel groups of ONE buffer (grouped head convs): one tensor in, one gradient
+    buffer out (cwf_head_loss_bwd_ex writes each map's group, padding zeroed) -- no per-map slices for autograd to reassemble."""
+
+    @staticmethod
+    def forward(ctx, label, posmasks, scale, ca, l_all):
+        K = backend()
+        G = len(posmasks)
+        total, _, coef = K.head_loss([l_all[..., q * ca:(q + 1) * ca] for q in range(G)], label, posmasks, scale)
+        ctx.posmasks, ctx.scale, ctx.ca = posmasks, scale, ca
+        ctx.save_for_backward(label, coef, l_all)
+        return total.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        label, coef, l_all = ctx.saved_tensors
+        G, ca = len(ctx.posmasks), ctx.ca
+        gs = g.reshape(1).to(torch.float32).contiguous()
+        d_all = torch.empty_like(l_all)
+        backend().head_loss_bwd([l_all[..., q * ca:(q + 1) * ca] for q in range(G)], label, ctx.posmasks, ctx.scale, coef, gs, grouped_out=(d_all, ca))
+        return None, None, None, None, d_all
+
+
 def head_group_loss(lazies, label, posmasks):
     """lazies: LazyProb maps of one supervision call (same shape / scale)."""
     label = label.contiguous()
     if label.dtype != torch.int64:
         label = label.long()
+    par = [z.parent for z in lazies]
+    if all(p is not None for p in par) and all(p[0] is par[0][0] for p in par) and [p[1] for p in par] == list(range(par[0][2])) \
+            and len(lazies) == par[0][2] and par[0][0].shape[-1] == par[0][2] * par[0][3]:
+        return _HeadGroupLossGFn.apply(label, tuple(int(m) for m in posmasks), lazies[0].scale, par[0][3], par[0][0])
     return _HeadGroupLossFn.apply(label, tuple(int(m) for m in posmasks), lazies[0].scale, *[z.logit for z in lazies])
 
 

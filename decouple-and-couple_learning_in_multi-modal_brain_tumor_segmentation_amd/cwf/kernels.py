@@ -259,6 +259,27 @@ class HipBackend:
                    sums.data_ptr(), _p(dx_add), a_ldc, dx.data_ptr(), c, n, d * h * w, c, self._stream())
         return dx
 
+    def conv_grouped(self, x_all, cin, wpks, biases, cout, y_all, x_goff, y_goff, w_refs=None, fwd_op=None, prec=None):
+        """G = len(wpks) channel-grouped 3x3x3 stride-1 convs in ONE launch (cwf_conv_mfma_bf16_grouped): group q reads channels
+        [q*x_goff, q*x_goff + cin) of x_all and writes channels [q*y_goff, q*y_goff + cout) of y_all (same voxel rows).  Data
+        gradients: pass the transposed packed weights (spec.packed(True)) and fwd_op.  Exact-fp32 mode: one launch per group."""
+        x_all, x_ldc = cl(x_all)
+        y, y_ldc = cl(y_all)
+        n, d, h, w, _ = x_all.shape
+        G = len(wpks)
+        mode = prec or ((_DGRAD_PRECISION or _PRECISION) if (fwd_op is not None) else _PRECISION)
+        if mode == "fp32":
+            for q in range(G):
+                self.conv(pk.CONV3_S1, x_all[..., q * x_goff:q * x_goff + cin], wpks[q], None if biases is None else biases[q], cout,
+                          out=y[..., q * y_goff:q * y_goff + cout], fwd_op=fwd_op, prec=mode)
+            return y_all
+        wp = (ctypes.c_void_p * G)(*[t.data_ptr() for t in wpks])
+        bp = (ctypes.c_void_p * G)(*[(0 if (biases is None or b is None) else b.data_ptr()) for b in (biases or [None] * G)])
+        self._call("cwf_conv_mfma_bf16_grouped", pk.CONV3_S1, 1 if mode == "bf16x3" else 0, x_all.data_ptr(), x_ldc, x_goff,
+                   ctypes.addressof(wp), ctypes.addressof(bp), y.data_ptr(), y_ldc, y_goff, G, n, d, h, w, cin, d, h, w, cout, self._stream())
+        return y_all
+
+
     # Weight gradients are leaves of the backward pass (only the optimizer reads them) while the data gradients form its
     # critical path.  With `wgrad_async` (opt-in: the caller must call join_wgrad_stream() before reading any .grad -- the
     # Trainer does) the weight-gradient kernels and their slab reductions go to a side stream and overlap the dgrad chain.
@@ -915,8 +936,10 @@ class HipBackend:
         """Fused head -> loss forward: logits = up to 3 low-res [N,d,h,w,ldc] tensors (2 channels used), label int64 [N,D,H,W].
         -> (total [1], loss [nm], coef [nm,N,2,4])"""
         nm = len(logits)
-        n, d, h, w, ldc = logits[0].shape
-        assert all(t.shape == logits[0].shape and t.is_contiguous() for t in logits) and label.is_contiguous()
+        n, d, h, w, _ = logits[0].shape
+        ldc = logits[0].stride(3)                  # (channel slices of one grouped logit buffer: rows ldc floats apart)
+        assert all(t.shape == logits[0].shape and t.stride() == logits[0].stride() and t.stride(4) == 1 for t in logits) and label.is_contiguous()
+        assert logits[0].stride(2) == w * ldc and logits[0].stride(1) == h * w * ldc and logits[0].stride(0) == d * h * w * ldc
         dev = logits[0].device
         sums = self._zeros_f64((nm, n, 2, 4), dev)
         ptrs = (ctypes.c_void_p * nm)(*[t.data_ptr() for t in logits])
@@ -929,17 +952,26 @@ class HipBackend:
                    d * h * w * scale ** 3, 2, self._stream())
         return total, loss, coef
 
-    def head_loss_bwd(self, logits, label, posmasks, scale, coef, gscale):
+    def head_loss_bwd(self, logits, label, posmasks, scale, coef, gscale, grouped_out=None):
+        """-> list of d(logit) tensors.  grouped_out = (buffer [N,d,h,w,nm*ca], ca): the gradients are written as channel groups of
+        that ONE buffer (ca channels each: 2 values + zeroed padding) and the returned tensors are its slices."""
         nm = len(logits)
-        n, d, h, w, ldc = logits[0].shape
+        n, d, h, w, ca = logits[0].shape
+        ldc = logits[0].stride(3)
         dev = logits[0].device
-        dls = [torch.empty_like(t) for t in logits]
+        if grouped_out is None:
+            dls = [torch.empty((n, d, h, w, ca), dtype=_f32, device=dev) for _ in logits]
+            dl_ca, dl_ldc = ca, ca
+        else:
+            buf, dl_ca = grouped_out
+            dl_ldc = buf.stride(3)
+            dls = [buf[..., m * dl_ca:(m + 1) * dl_ca] for m in range(nm)]
         ws = self.workspace("head_loss_bwd", nm * n * d * scale * h * w * 2, dev)
         ptrs = (ctypes.c_void_p * nm)(*[t.data_ptr() for t in logits])
         dptrs = (ctypes.c_void_p * nm)(*[t.data_ptr() for t in dls])
         masks = (ctypes.c_uint32 * nm)(*[int(m) for m in posmasks])
-        self._call("cwf_head_loss_bwd", ctypes.addressof(ptrs), nm, ldc, ctypes.addressof(masks), label.data_ptr(), coef.data_ptr(), gscale.data_ptr(),
-                   ctypes.addressof(dptrs), ldc, ws.data_ptr(), n, d, h, w, scale, self._stream())
+        self._call("cwf_head_loss_bwd_ex", ctypes.addressof(ptrs), nm, ldc, ctypes.addressof(masks), label.data_ptr(), coef.data_ptr(), gscale.data_ptr(),
+                   ctypes.addressof(dptrs), dl_ca, dl_ldc, ws.data_ptr(), n, d, h, w, scale, self._stream())
         return dls
 
     # ------------------------------------------------------------------ N1 (sliding-window inference glue)

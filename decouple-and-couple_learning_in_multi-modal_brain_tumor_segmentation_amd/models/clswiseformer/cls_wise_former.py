@@ -19,6 +19,8 @@ Deliberate relaxations of reference limitations:
   * the always-on stem dropout (F4) is kept by default; set ``model.Unet_list.InitConv.dropout = 0.0`` to disable.
 Returned tensors are logical NC(DHW) views of channels-last (NDHWC) memory.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -133,6 +135,8 @@ class ClsWiseFormer(nn.Module):
 
     def _heads3(self, heads, feats_all):
         """the three sub-regions' supervision heads on the channel groups of one tensor (zero-copy slices)"""
+        if os.environ.get("CWF_GROUPED_HEADS", "1") == "1":
+            return heads.heads3(feats_all)               # both conv stages as one channel-grouped launch each way
         parts = CP.split_channels3(feats_all)
         return {r: heads.head(k, p) for r, k, p in zip(REGIONS, (1, 2, 4), parts)}
 

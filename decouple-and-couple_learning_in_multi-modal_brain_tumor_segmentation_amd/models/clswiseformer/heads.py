@@ -23,6 +23,24 @@ class _Heads(nn.Module):
         return prob.permute(0, 4, 1, 2, 3)        # logical [N,2,D,H,W], channels-last memory
 
 
+    def _heads3(self, firsts, seconds, x_all):
+        """The three sub-regions' heads on the channel groups of ONE tensor [N,d,h,w,3*C]: both conv stages as channel-grouped
+        launches (CF.grouped_conv); in training mode the three lazy maps share the grouped logit buffer (one fused loss call)."""
+        G = len(firsts)
+        h_all = CF.grouped_conv(x_all, firsts)
+        l_all = CF.grouped_conv(h_all, seconds)           # [N,d,h,w,G*4]: 2 logits + 2 pad channels per region
+        ca = l_all.shape[-1] // G
+        out = {}
+        lazy = self.training and self.lazy_training_maps and torch.is_grad_enabled()
+        for q, r in enumerate(("01", "02", "04")):
+            logit = l_all[..., q * ca:(q + 1) * ca]
+            if lazy:
+                out[r] = CF.LazyProb(logit, 2, self.sample_scale, parent=(l_all, q, G, ca))
+            else:
+                out[r] = CF.upsample_softmax(logit.contiguous(), 2, self.sample_scale).permute(0, 4, 1, 2, 3)
+        return out
+
+
 class SuperviseLabel(_Heads):
     def head(self, k, x):
         """One sub-region's head (k in {1,2,4})."""
@@ -34,6 +52,9 @@ class SuperviseLabel(_Heads):
             setattr(self, "supervise_label_%d" % k, HipConv(item_future_num, 32))
             setattr(self, "down_label_%d" % k, HipConv(32, 2))
         self.sample_scale = 8
+
+    def heads3(self, x_all):
+        return self._heads3([getattr(self, "supervise_label_%d" % k) for k in (1, 2, 4)], [getattr(self, "down_label_%d" % k) for k in (1, 2, 4)], x_all)
 
     def forward(self, s01, s02, s04):
         return {"01": self._head(self.supervise_label_1, self.down_label_1, s01),
@@ -51,6 +72,9 @@ class EdgeSuperviseLabel(_Heads):
             setattr(self, "edge_supervise_label_%d" % k, HipConv(item_future_num, 8))
             setattr(self, "edge_down_label_%d" % k, HipConv(8, 2))
         self.sample_scale = 4
+
+    def heads3(self, x_all):
+        return self._heads3([getattr(self, "edge_supervise_label_%d" % k) for k in (1, 2, 4)], [getattr(self, "edge_down_label_%d" % k) for k in (1, 2, 4)], x_all)
 
     def forward(self, e01, e02, e04):
         return {"01": self._head(self.edge_supervise_label_1, self.edge_down_label_1, e01),

@@ -112,6 +112,14 @@ int cwf_conv_mfma_bf16_nb(int op, int x3,
                           const float* nb_x, int nb_ldc, const float* nb_scale, const float* nb_shift, float nb_slope,
                           int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
                           void* stream);
+/* Channel-grouped 3x3x3 stride-1 conv (op = CWF_CONV3_S1; forward, or the data gradient through the transposed packed weights):
+ * `groups` (2 or 3) independent convs Cin -> Cout, group q reading input channels [q*x_goff, q*x_goff + Cin) and writing output
+ * channels [q*y_goff, q*y_goff + Cout) of the same voxel rows, each with its own packed weights / bias (h_wpk16, h_bias: HOST arrays
+ * of `groups` device pointers; h_bias or its entries may be NULL) -- one launch for the three sub-regions' supervision-head convs
+ * (SuperviseLabel.py:58-81, EdgeSuperviseLabel.py:56-76).  Bias only: no prologue, residual, out_scale or statistics. */
+int cwf_conv_mfma_bf16_grouped(int op, int x3, const float* x, int x_ldc, int x_goff, const void* const* h_wpk16, const float* const* h_bias,
+                               float* y, int y_ldc, int y_goff, int groups,
+                               int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, void* stream);
 int cwf_wgrad_mfma_bf16(int op, int x3,
                         const float* x, int x_ldc, const float* in_scale, const float* in_shift, float in_slope,
                         const float* dy, int dy_ldc, float* partial,
@@ -355,6 +363,11 @@ int cwf_head_loss_sums(const float* const* h_logits, int nmaps, int l_ldc, const
 int cwf_head_loss_bwd(const float* const* h_logits, int nmaps, int l_ldc, const uint32_t* h_posmasks, const int64_t* label,
                       const float* coef, const float* gscale, float* const* h_dlogits, int dl_ldc, float* workspace,
                       int N, int D, int H, int W, int scale, void* stream);
+/* Same, the maps being channel groups of ONE gradient buffer: dl_ca channels written per voxel (2 gradients + zeroed padding), voxel
+ * rows dl_ldc floats apart (what the channel-grouped head convs below consume). */
+int cwf_head_loss_bwd_ex(const float* const* h_logits, int nmaps, int l_ldc, const uint32_t* h_posmasks, const int64_t* label,
+                         const float* coef, const float* gscale, float* const* h_dlogits, int dl_ca, int dl_ldc, float* workspace,
+                         int N, int D, int H, int W, int scale, void* stream);
 int cwf_dice_ce_bwd(const float* prob, const int64_t* label, uint32_t posmask, const float* coef, const float* gscale,
                     float* dprob, int N, int64_t V, int C, void* stream);
 

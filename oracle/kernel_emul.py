@@ -132,6 +132,20 @@ class EmulBackend:
         out.copy_(g + residual if residual is not None else g)
         return out
 
+
+    def conv_grouped(self, x_all, cin, wpks, biases, cout, y_all, x_goff, y_goff, w_refs=None, fwd_op=None, prec=None):
+        """cwf_conv_mfma_bf16_grouped: G channel-grouped 3x3x3 stride-1 convs (or their data gradients) -- one conv per group"""
+        assert w_refs is not None
+        for q, w in enumerate(w_refs):
+            xs = x_all[..., q * x_goff:q * x_goff + cin]
+            if fwd_op is None:
+                y = self.conv(CONV3_S1, xs, None, None if biases is None else biases[q], cout, w_ref=w)
+                y_all[..., q * y_goff:q * y_goff + cout] = y[..., :cout]
+            else:
+                out = torch.empty(y_all.shape[:-1] + (cout,), dtype=torch.float32)
+                self.conv(CONV3_S1, xs, None, None, cout, out=out, w_ref=w, fwd_op=fwd_op)
+                y_all[..., q * y_goff:q * y_goff + cout] = out
+        return y_all
     def wgrad(self, op, x, in_scale, in_shift, slope, dy, cout, inv_map, has_bias_map, w_numel, w_ref_shape=None, prec=None, allow_async=False):
         """cwf_wgrad_mfma + cwf_wgrad_reduce: weight / bias halves of aten::convolution_backward on act(IN(x))."""
         xa = _prologue(x, in_scale, in_shift, slope).detach()
@@ -608,13 +622,18 @@ class EmulBackend:
             total = total + v
         return total, loss, torch.stack([o[1] for o in outs])
 
-    def head_loss_bwd(self, logits, label, posmasks, scale, coef, gscale):
+    def head_loss_bwd(self, logits, label, posmasks, scale, coef, gscale, grouped_out=None):
         dls = []
         for m, (lg, pm) in enumerate(zip(logits, posmasks)):
             prob = self.upsample_softmax(lg, 2, scale)
             dprob = self.dice_ce_bwd(prob, label, int(pm), coef[m], gscale)
             n, d, h, w, ldc = lg.shape
-            dls.append(self.upsample_softmax_bwd(dprob, prob, (n, d, h, w), 2, scale, ldc))
+            dl = self.upsample_softmax_bwd(dprob, prob, (n, d, h, w), 2, scale, ldc)
+            if grouped_out is not None:                     # channel groups of one gradient buffer (cwf_head_loss_bwd_ex)
+                buf, ca = grouped_out
+                buf[..., m * ca:(m + 1) * ca] = dl[..., :ca]
+                dl = buf[..., m * ca:(m + 1) * ca]
+            dls.append(dl)
         return dls
 
     # ------------------------------------------------------------------ K11 / misc

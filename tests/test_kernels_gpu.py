@@ -280,6 +280,65 @@ def test_pointwise_weight_gradient_stream(hip, op, cin, cout, size, n, prec):
     close(gw2, gw_ref, rtol=5e-5, what="wgrad strided")
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("cin,cout,size,n,G", [
+    (128, 32, (8, 8, 16), 2, 3),                 # label heads, first stage
+    (32, 2, (8, 8, 16), 2, 3),                   # second stage: 2 logits in 4-channel groups
+    (32, 8, (8, 12, 16), 1, 3),                  # edge heads
+    (8, 2, (8, 12, 16), 2, 3),                   # <= 16 channels: conv16 tap order of the packed weights
+    (16, 16, (6, 8, 20), 1, 2),                  # two groups, ragged tiles
+])
+def test_channel_grouped_conv(hip, cin, cout, size, n, G, prec):
+    """cwf_conv_mfma_bf16_grouped (forward and data gradient) against one oracle conv per group; other channels of the output
+    buffer stay untouched."""
+    tol = PREC_TOL[prec]
+    from cwf import functional as CF
+    d, h, w_ = size
+    ca = (cout + 3) // 4 * 4
+    x_all = rnd(n, d, h, w_, G * cin, seed=61)
+    ws = [rnd(cout, cin, 3, 3, 3, seed=62 + q, scale=1.0 / math.sqrt(27 * cin)) for q in range(G)]
+    bs = [rnd(cout, seed=72 + q, scale=0.1) for q in range(G)]
+    specs = [_packed(CF.ConvSpec(pk.CONV3_S1, cin, cout), w, prec) for w in ws]
+    wf = [(s_.wpk_f if prec == "fp32" else s_.wpk16_f) for s_ in specs]
+    wd = [(s_.wpk_d if prec == "fp32" else s_.wpk16_d) for s_ in specs]
+    y_all = torch.full((n, d, h, w_, G * ca), 5.0, device=DEV)
+    hip.conv_grouped(x_all.to(DEV), cin, wf, [b.to(DEV) for b in bs], cout, y_all, x_goff=cin, y_goff=ca, prec=prec)
+    for q in range(G):
+        ref = E.conv(pk.CONV3_S1, x_all[..., q * cin:(q + 1) * cin], None, bs[q], cout, w_ref=ws[q])
+        close(y_all[..., q * ca:q * ca + cout], ref[..., :cout], rtol=tol, what="fwd group %d" % q)
+        if ca != cout:
+            assert bool((y_all[..., q * ca + cout:(q + 1) * ca] == 5.0).all())
+    dy_all = torch.zeros(n, d, h, w_, G * ca)
+    for q in range(G):
+        dy_all[..., q * ca:q * ca + cout] = rnd(n, d, h, w_, cout, seed=82 + q)
+    dx_all = torch.empty((n, d, h, w_, G * cin), device=DEV)
+    hip.conv_grouped(dy_all.to(DEV), ca, wd, None, cin, dx_all, x_goff=ca, y_goff=cin, fwd_op=pk.CONV3_S1, prec=prec)
+    for q in range(G):
+        ref = E.conv(pk.CONV3_S1, dy_all[..., q * ca:(q + 1) * ca], None, None, cin, out=torch.empty(n, d, h, w_, cin), w_ref=ws[q], fwd_op=pk.CONV3_S1)
+        close(dx_all[..., q * cin:(q + 1) * cin], ref, rtol=tol, what="dgrad group %d" % q)
+
+
+def test_head_loss_backward_into_channel_groups(hip):
+    """cwf_head_loss_bwd_ex: the three maps' logit gradients written as 4-channel groups of one [N,d,h,w,12] buffer (2 values + zeroed
+    padding each) equal the per-map tensors of cwf_head_loss_bwd; forward sums from the strided slices equal the contiguous ones."""
+    n, (d, h, w_), scale = 2, (4, 4, 8), 4
+    l_all = rnd(n, d, h, w_, 12, seed=91).to(DEV)
+    label = torch.randint(0, 4, (n, d * scale, h * scale, w_ * scale), generator=torch.Generator().manual_seed(5)).to(DEV)
+    masks = (0b0010, 0b0100, 0b1000)
+    slices = [l_all[..., 4 * q:4 * q + 4] for q in range(3)]
+    conts = [s_.contiguous() for s_ in slices]
+    t0, l0, c0 = hip.head_loss(conts, label, masks, scale)
+    t1, l1, c1 = hip.head_loss(slices, label, masks, scale)
+    assert torch.equal(l0, l1) and torch.equal(c0, c1)
+    gs = torch.full((1,), 0.7, device=DEV)
+    ref = hip.head_loss_bwd(conts, label, masks, scale, c0, gs)
+    d_all = torch.full_like(l_all, 9.0)
+    outs = hip.head_loss_bwd(slices, label, masks, scale, c0, gs, grouped_out=(d_all, 4))
+    for q in range(3):
+        assert torch.equal(d_all[..., 4 * q:4 * q + 4], ref[q]) and outs[q].data_ptr() == d_all[..., 4 * q:4 * q + 4].data_ptr()
+        assert bool((d_all[..., 4 * q + 2:4 * q + 4] == 0).all())
+
+
 def test_gather_batched_matches_index_maps(hip):
     from cwf import functional as CF
     packer = CF.WeightPacker()
