@@ -23,6 +23,10 @@ struct WgArgsB {
   int ngroups, tiles_per_split, total_tiles;
   int64_t slab_floats;
   int cls_slab_base[8];
+  // grouped launches (cwf_wgrad_mfma_bf16_grouped: the three sub-regions' head layers): blockIdx.z = group, each with its own
+  // x / dy / slab buffer; single-class (3x3x3 stride-1) operators only.  groups == 0: an ordinary launch (blockIdx.z = class)
+  int groups;
+  const float* x_g[3]; const float* dy_g[3]; float* partial_g[3];
 };
 
 __device__ __forceinline__ unsigned pack_bf16w(float a, float b) {
@@ -72,7 +76,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgsB a) {
   const int bq = (lane & 15) >> 2, bp = lane & 3;        // transposed-read block row / column quad supplied by this lane
   const int split = blockIdx.x;
   const int chunk = blockIdx.y / a.ngroups, grp = blockIdx.y % a.ngroups;
-  const int cls = blockIdx.z;
+  const int cls = a.groups ? 0 : blockIdx.z;
+  const float* ax_ = a.groups ? a.x_g[blockIdx.z] : a.x;             // (workgroup-uniform: group operands)
+  const float* ady_ = a.groups ? a.dy_g[blockIdx.z] : a.dy;
+  float* apart_ = a.groups ? a.partial_g[blockIdx.z] : a.partial;
   const int Dc = g.cls_dims[cls][0], Hc = g.cls_dims[cls][1], Wc = g.cls_dims[cls][2];
   const int ntaps = g.cls_ntaps[cls];
   const int* tapofs = g.tapofs + (g.ncls > 1 ? cls * 8 : 0);
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgsB a) {
   const int tiles_sp = g.tiles_d * g.tiles_h * g.tiles_w;
   const int t_begin = split * a.tiles_per_split;
   const int t_end = min(a.total_tiles, t_begin + a.tiles_per_split);
-  const bool vec_dy = (a.dy_ldc & 3) == 0 && (((uintptr_t)a.dy) & 15) == 0;
+  const bool vec_dy = (a.dy_ldc & 3) == 0 && (((uintptr_t)ady_) & 15) == 0;
   const int of0 = g.cls_ooff[cls][0], of1 = g.cls_ooff[cls][1], of2 = g.cls_ooff[cls][2];
 
   // ones operand for the bias row: bf16 1.0 = 0x3F80
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgsB a) {
         const int iw = v & 15, ih = (v >> 4) & 3, idd = v >> 6;
         const int gd = id0 + idd, gh = ih0 + ih, gw = iw0 + iw;
         const bool ok = cval && gd >= 0 && gd < g.Di && gh >= 0 && gh < g.Hi && gw >= 0 && gw < g.Wi;
-        const float* px = a.x + ((((int64_t)n * g.Di + gd) * g.Hi + gh) * g.Wi + gw) * g.x_ldc + c;
+        const float* px = ax_ + ((((int64_t)n * g.Di + gd) * g.Hi + gh) * g.Wi + gw) * g.x_ldc + c;
         vx[i] = ok ? *reinterpret_cast<const float4*>(px) : make_float4(0.f, 0.f, 0.f, 0.f);
         okx |= ok ? (1u << i) : 0u;
       }
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgsB a) {
         const int co = co0 + cq * 4;
         const bool ok = od < Dc && oh < Hc && ow < Wc && co < g.Cout;
         const int64_t gv = (((int64_t)n * g.Do + (od * g.os + of0)) * g.Ho + (oh * g.os + of1)) * g.Wo + (ow * g.os + of2);
-        const float* pd = a.dy + gv * a.dy_ldc + co;
+        const float* pd = ady_ + gv * a.dy_ldc + co;
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok) {
           if (vec_dy && co + 3 < g.y_ldc) {
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgsB a) {
         const int gd = id0 + idd, gh = ih0 + ih, gw = iw0 + iw;
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
         if (cval && gd >= 0 && gd < g.Di && gh >= 0 && gh < g.Hi && gw >= 0 && gw < g.Wi) {
-          val = *reinterpret_cast<const float4*>(a.x + ((((int64_t)n * g.Di + gd) * g.Hi + gh) * g.Wi + gw) * g.x_ldc + c);
+          val = *reinterpret_cast<const float4*>(ax_ + ((((int64_t)n * g.Di + gd) * g.Hi + gh) * g.Wi + gw) * g.x_ldc + c);
           if (has_norm || a.in_slope != 1.f) {
             val.x = cwf_act(val.x * sc.x + sh.x, a.in_slope); val.y = cwf_act(val.y * sc.y + sh.y, a.in_slope);
             val.z = cwf_act(val.z * sc.z + sh.z, a.in_slope); val.w = cwf_act(val.w * sc.w + sh.w, a.in_slope);
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgsB a) {
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
       if (od < Dc && oh < Hc && ow < Wc && co < g.Cout) {
         const int64_t gv = (((int64_t)n * g.Do + (od * g.os + of0)) * g.Ho + (oh * g.os + of1)) * g.Wo + (ow * g.os + of2);
-        const float* p = a.dy + gv * a.dy_ldc + co;
+        const float* p = ady_ + gv * a.dy_ldc + co;
         if (vec_dy && co + 3 < g.y_ldc) {
           val = *reinterpret_cast<const float4*>(p);
           if (co + 1 >= g.Cout) val.y = 0.f;
@@ -388,7 +395,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgsB a) {
     }
   }
 
-  float4* out = reinterpret_cast<float4*>(a.partial + (int64_t)(TAPSPLIT ? split : split * 4 + wave) * a.slab_floats);
+  float4* out = reinterpret_cast<float4*>(apart_ + (int64_t)(TAPSPLIT ? split : split * 4 + wave) * a.slab_floats);
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
     const int t = TAPSPLIT ? wave + 4 * i : i;
@@ -744,6 +751,9 @@ __global__ __launch_bounds__(256 + 64 * WS1_LW) void wgrad_s1_kernel(const WgArg
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int split = blockIdx.x;
   const int chunk = blockIdx.y / a.ngroups, grp = blockIdx.y % a.ngroups;
+  const float* ax_ = a.groups ? a.x_g[blockIdx.z] : a.x;             // (workgroup-uniform: group operands of a grouped launch)
+  const float* ady_ = a.groups ? a.dy_g[blockIdx.z] : a.dy;
+  float* apart_ = a.groups ? a.partial_g[blockIdx.z] : a.partial;
   const int co0 = grp * CGW;
   const int tiles_sp = g.tiles_d * g.tiles_h * g.tiles_w;
   const int t_begin = split * a.tiles_per_split;
@@ -812,7 +822,7 @@ __global__ __launch_bounds__(256 + 64 * WS1_LW) void wgrad_s1_kernel(const WgArg
       }
     }
     // ---- slab (layout of wgrad_bf16_kernel: block = (chunk, group, tap, tile))
-    float4* out = reinterpret_cast<float4*>(a.partial + (int64_t)split * a.slab_floats);
+    float4* out = reinterpret_cast<float4*>(apart_ + (int64_t)split * a.slab_floats);
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
       const int t = wave + 4 * i;
@@ -865,8 +875,8 @@ __global__ __launch_bounds__(256 + 64 * WS1_LW) void wgrad_s1_kernel(const WgArg
       const int tile_h = rem % g.tiles_h; const int tile_d = rem / g.tiles_h;
       const int od0 = tile_d * 4, oh0 = tile_h * 4, ow0 = tile_w * 16;
       const int id0 = od0 - 1, ih0 = oh0 - 1, iw0 = ow0 - 1;
-      const float* xb = a.x + ((((int64_t)n * g.Di + id0) * g.Hi + ih0) * g.Wi + iw0) * g.x_ldc;
-      const float* db = a.dy + ((((int64_t)n * g.Do + od0) * g.Ho + oh0) * g.Wo + ow0) * a.dy_ldc;
+      const float* xb = ax_ + ((((int64_t)n * g.Di + id0) * g.Hi + ih0) * g.Wi + iw0) * g.x_ldc;
+      const float* db = ady_ + ((((int64_t)n * g.Do + od0) * g.Ho + oh0) * g.Wo + ow0) * a.dy_ldc;
       if (has_norm && cval) {
         sc[SET] = *reinterpret_cast<const float4*>(a.in_scale + (int64_t)n * g.Cin + c);
         sh[SET] = *reinterpret_cast<const float4*>(a.in_shift + (int64_t)n * g.Cin + c);
@@ -876,7 +886,7 @@ __global__ __launch_bounds__(256 + 64 * WS1_LW) void wgrad_s1_kernel(const WgArg
       for (int i = 0; i < XS; ++i) {
         const int gd = id0 + (int)((xo[i] >> 16) & 7u), gh = ih0 + (int)((xo[i] >> 19) & 7u), gw = iw0 + (int)(xo[i] >> 22);
         const bool ok = cval && (i < XS - 1 || last_x) && (unsigned)gd < (unsigned)g.Di && (unsigned)gh < (unsigned)g.Hi && (unsigned)gw < (unsigned)g.Wi;
-        vx[SET][i] = *reinterpret_cast<const float4*>(ok ? xb + relx[i] : a.x);      // unconditional load, masked at conversion
+        vx[SET][i] = *reinterpret_cast<const float4*>(ok ? xb + relx[i] : ax_);      // unconditional load, masked at conversion
         mx |= ok ? (1u << i) : 0u;
       }
 #pragma unroll
@@ -884,7 +894,7 @@ __global__ __launch_bounds__(256 + 64 * WS1_LW) void wgrad_s1_kernel(const WgArg
         const int m = m0 + k * DROWS;
         const bool ok = co_ok && od0 + (m >> 2) < g.Do && oh0 + (m & 3) < g.Ho && ow0 + tw < g.Wo;
         const int rel = reld0 + ((((m >> 2) - (m0 >> 2)) * g.Ho + ((m & 3) - (m0 & 3))) * g.Wo) * a.dy_ldc;
-        vd[SET][k] = *reinterpret_cast<const float4*>(ok ? db + rel : a.dy);
+        vd[SET][k] = *reinterpret_cast<const float4*>(ok ? db + rel : ady_);
         md |= ok ? (1u << k) : 0u;
       }
       okx[SET] = mx; okd[SET] = md;
@@ -1108,9 +1118,35 @@ static int launch_pw_wgrad(const WgArgsB& a, int CG, int max_slabs, int* nsplit_
 extern "C" int cwf_wgrad_nsplit(int op, int N, int Do, int Ho, int Wo, int Cin, int Cout);
 extern "C" int64_t cwf_wgrad_slab_floats(int op, int Cin, int Cout);
 
+static int wgrad_bf16_impl(int op, int x3, const float* x, int x_ldc, const float* in_scale, const float* in_shift, float in_slope,
+                           const float* dy, int dy_ldc, float* partial,
+                           int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int* nsplit_used, void* stream,
+                           int groups, const float* const* xg, const float* const* dyg, float* const* pg);
+
 extern "C" int cwf_wgrad_mfma_bf16(int op, int x3, const float* x, int x_ldc, const float* in_scale, const float* in_shift, float in_slope,
                                    const float* dy, int dy_ldc, float* partial,
                                    int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int* nsplit_used, void* stream) {
+  return wgrad_bf16_impl(op, x3, x, x_ldc, in_scale, in_shift, in_slope, dy, dy_ldc, partial, N, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, nsplit_used, stream,
+                         0, nullptr, nullptr, nullptr);
+}
+
+// `groups` (2 or 3) same-shape 3x3x3 stride-1 layers in ONE launch (blockIdx.z = group): group q has its own activation view x[q]
+// (row pitch x_ldc), gradient view dy[q] (row pitch dy_ldc) and slab buffer partial[q] (each sized like a single layer's); no
+// normalising prologue.  h_x / h_dy / h_partial: HOST arrays of device pointers.  The three sub-regions' supervision-head layers.
+extern "C" int cwf_wgrad_mfma_bf16_grouped(int op, int x3, const float* const* h_x, int x_ldc, const float* const* h_dy, int dy_ldc,
+                                           float* const* h_partial, int groups,
+                                           int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int* nsplit_used, void* stream) {
+  if (!h_x || !h_dy || !h_partial || groups < 2 || groups > 3 || op != CWF_CONV3_S1) return CWF_E_BADARG;
+  for (int q = 0; q < groups; ++q)
+    if (!h_x[q] || !h_dy[q] || !h_partial[q] || ((uintptr_t)h_x[q] & 15) || ((uintptr_t)h_partial[q] & 15)) return CWF_E_ALIGN;
+  return wgrad_bf16_impl(op, x3, h_x[0], x_ldc, nullptr, nullptr, 1.f, h_dy[0], dy_ldc, h_partial[0], N, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, nsplit_used,
+                         stream, groups, h_x, h_dy, h_partial);
+}
+
+static int wgrad_bf16_impl(int op, int x3, const float* x, int x_ldc, const float* in_scale, const float* in_shift, float in_slope,
+                           const float* dy, int dy_ldc, float* partial,
+                           int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int* nsplit_used, void* stream,
+                           int groups, const float* const* xg, const float* const* dyg, float* const* pg) {
   if (!x || !dy || !partial || N <= 0) return CWF_E_BADARG;
   if ((Cin & 3) || (x_ldc & 3) || ((uintptr_t)x & 15) || ((uintptr_t)partial & 15)) return CWF_E_ALIGN;
   if (in_scale && !in_shift) return CWF_E_BADARG;
@@ -1135,8 +1171,15 @@ extern "C" int cwf_wgrad_mfma_bf16(int op, int x3, const float* x, int x_ldc, co
     return CWF_E_BADARG;
   a.x = x; a.in_scale = in_scale; a.in_shift = in_shift; a.in_slope = in_slope; a.dy = dy; a.dy_ldc = dy_ldc; a.partial = partial;
   a.ngroups = ngroups; a.tiles_per_split = tps; a.total_tiles = total; a.slab_floats = blocks * 256;
+  a.groups = groups;
+  bool dy_al = (((uintptr_t)dy) & 15) == 0;
+  for (int q = 0; q < 3; ++q) {
+    a.x_g[q] = (groups && q < groups) ? xg[q] : nullptr; a.dy_g[q] = (groups && q < groups) ? dyg[q] : nullptr; a.partial_g[q] = (groups && q < groups) ? pg[q] : nullptr;
+    if (groups && q < groups && (((uintptr_t)dyg[q]) & 15)) dy_al = false;
+  }
+  const int gz = groups ? groups : ncls;                 // grid z: group (grouped launches are single-class) or parity class
   if (nsplit_used) *nsplit_used = tapsplit ? wg_splits : wg_splits * 4;
-  if (op == CWF_CONV3_S1 && Cin <= 16 && Cout == 16 && (dy_ldc & 3) == 0 && (((uintptr_t)dy) & 15) == 0 && (int64_t)Do * Ho * Wo >= 32768) {
+  if (!groups && op == CWF_CONV3_S1 && Cin <= 16 && Cout == 16 && (dy_ldc & 3) == 0 && (((uintptr_t)dy) & 15) == 0 && (int64_t)Do * Ho * Wo >= 32768) {
     // full-resolution 16-channel layers: persistent producer/consumer kernel, one slab per workgroup (<= 256 <= generic nsplit)
     int grid = 256; while (grid > 8 && grid > total) grid -= 8;      // multiple of 8 (XCD-aware tile map)
     const size_t lds16 = (size_t)2 * (36 * W16_XW * 16 + 16 * W16_DW * 16) * sizeof(unsigned short) * (x3 ? 2 : 1);
@@ -1153,7 +1196,7 @@ extern "C" int cwf_wgrad_mfma_bf16(int op, int x3, const float* x, int x_ldc, co
     if (nsplit_used) *nsplit_used = grid;
     return 0;
   }
-  if ((op == CWF_CONV1 || op == CWF_CONVT2) && ((int64_t)Di * Hi * Wi & 3) == 0 && (op == CWF_CONV1 || (Wi & 3) == 0) &&
+  if (!groups && (op == CWF_CONV1 || op == CWF_CONVT2) && ((int64_t)Di * Hi * Wi & 3) == 0 && (op == CWF_CONV1 || (Wi & 3) == 0) &&
       (int64_t)Di * Hi * Wi * (x_ldc > 8 * dy_ldc ? x_ldc : 8 * dy_ldc) < (1ll << 31)) {
     // pointwise layers: stream kernel (fp32 MFMA straight from global memory, every operand read once), both precision modes
     static const bool off = getenv("CWF_NO_PW_WGRAD") != nullptr;        // A/B switch (diagnostics)
@@ -1175,7 +1218,7 @@ extern "C" int cwf_wgrad_mfma_bf16(int op, int x3, const float* x, int x_ldc, co
     if (r >= 0) return r;
   }
   if (!x3 && op == CWF_CONV3_S1 && CG <= 2 && a.g.TD == 4 && a.g.TH == 4 && a.g.ID == 6 && a.g.IH == 6 && a.g.IW == 18 && (Cout & 3) == 0 &&
-      (dy_ldc & 3) == 0 && (((uintptr_t)dy) & 15) == 0) {
+      (dy_ldc & 3) == 0 && dy_al) {
     static const bool off = getenv("CWF_NO_WGRAD_S1") != nullptr;       // A/B switch (diagnostics)
     if (!off) {
       // producer / consumer kernel: ~256 eight-wave workgroups in all (one per CU), each a contiguous tile range of one (chunk, group)
@@ -1185,7 +1228,7 @@ extern "C" int cwf_wgrad_mfma_bf16(int op, int x3, const float* x, int x_ldc, co
         a.tiles_per_split = tps1;
         if (nsplit_used) *nsplit_used = splits1;
         const size_t lds1 = (size_t)2 * (36 * 20 * 16 + 16 * (CG == 1 ? 20 : 16) * CG * 16 + (16 / 2 + 1) * (CG == 2 ? 16 : 0)) * sizeof(unsigned short);
-        dim3 grid1(splits1, nchunks * ngroups, 1);
+        dim3 grid1(splits1, nchunks * ngroups, groups ? groups : 1);
         hipStream_t st1 = cwf_stream(stream);
         static bool attr1 = false;
         if (!attr1) {
@@ -1204,7 +1247,7 @@ extern "C" int cwf_wgrad_mfma_bf16(int op, int x3, const float* x, int x_ldc, co
   const size_t dimg = (size_t)a.g.TD * a.g.TH * wg_dy_pitch(CG * 16) * CG * 16 + (size_t)(a.g.TD * a.g.TH / 2 + 1) * wg_dy_skew(CG * 16);
   const size_t lds = (ximg + dimg) * sizeof(unsigned short) * (x3 ? 2 : 1);
   if (lds > 160 * 1024) return CWF_E_TOOLARGE;
-  dim3 grid(wg_splits, nchunks * ngroups, ncls);
+  dim3 grid(wg_splits, nchunks * ngroups, gz);
   hipStream_t st = cwf_stream(stream);
 #define CWF_WG(tpw, ntw, ts, xx) do { static bool attr = false; \
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<tpw, ntw, ts, xx>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \

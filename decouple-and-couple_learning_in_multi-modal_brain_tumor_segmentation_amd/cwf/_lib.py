@@ -85,6 +85,7 @@ SIGNATURES = {
     "cwf_head_loss_sums": [P, I, I, P, P, P, I, I, I, I, I, P],
     "cwf_head_loss_bwd": [P, I, I, P, P, P, P, P, I, P, I, I, I, I, I, P],
     "cwf_head_loss_bwd_ex": [P, I, I, P, P, P, P, P, I, I, P, I, I, I, I, I, P],
+    "cwf_wgrad_mfma_bf16_grouped": [I, I, P, I, P, I, P, I, I, I, I, I, I, I, I, I, I, P, P],
     "cwf_conv_mfma_bf16_grouped": [I, I, P, I, I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
     "cwf_ln_pair_fwd_g": [P, P, I, P, I, P, P, P, I, I, F, P],
     "cwf_ln_pair_bwd_g": [P, P, P, P, P, I, P, I, P, P, P, I, I, I, P],

@@ -366,7 +366,20 @@ class _GroupedConvFn(torch.autograd.Function):
         dy_all = dy_all.contiguous()
         sink = active_sink()
         grads = []
-        for q, spec in enumerate(specs):
+        views = None
+        if sink is not None and all(spec.uses <= 1 and spec.has_bias_map for spec in specs) and all(ctx.needs_input_grad[2:]):
+            views = [(sink.view(wb[2 * q]), sink.view(wb[2 * q + 1])) for q in range(G)]
+            if any(v[0] is None or v[1] is None for v in views):
+                views = None
+        if views is not None:
+            # gradient-sink path: the G layers' slabs in ONE launch (their reductions are rows of the phase's batched reduce)
+            K.wgrad_to_grouped(list(specs), s0.op, [x_all[..., q * cin:(q + 1) * cin] for q in range(G)],
+                               [dy_all[..., q * ca:q * ca + cout] for q in range(G)], cout, [spec.inv_map for spec in specs],
+                               [v[0] for v in views], [v[1] for v in views], allow_async=True)
+            for q in range(G):
+                sink.mark(wb[2 * q]); sink.mark(wb[2 * q + 1])
+            grads = [None, None] * G
+        for q, spec in enumerate(specs if views is None else ()):
             w, b = wb[2 * q], wb[2 * q + 1]
             xs = x_all[..., q * cin:(q + 1) * cin]
             dys = dy_all[..., q * ca:q * ca + cout]

@@ -370,6 +370,54 @@ class HipBackend:
             nsplit = used.value
         self._wg_pending.append((part.data_ptr(), inv_map.data_ptr(), dw_dst.data_ptr(), _p(db_dst), int(slab), int(nsplit)))
 
+    def wgrad_to_grouped(self, keys, op, xs, dys, cout, inv_maps, dw_dsts, db_dsts, prec=None, allow_async=False):
+        """wgrad_to for G same-shape 3x3x3 stride-1 layers without prologue (channel-group views xs[q] / dys[q] of shared buffers):
+        ONE slab launch (cwf_wgrad_mfma_bf16_grouped); each layer keeps its own slab buffer and row in the batched reduce."""
+        mode = prec or _WGRAD_PRECISION or _PRECISION
+        if mode == "fp32" or (self.wgrad_async and allow_async and self.wgrad_defer):
+            for q in range(len(keys)):
+                self.wgrad_to(keys[q], op, xs[q], None, None, 1.0, dys[q], cout, inv_maps[q], dw_dsts[q], db_dsts[q], prec=prec, allow_async=allow_async)
+            return
+        if self.wgrad_async and allow_async:
+            dev = xs[0].device
+            side = self.wgrad_stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                self._wgrad_to_grouped_impl(keys, op, xs, dys, cout, inv_maps, dw_dsts, db_dsts, mode)
+            for t in list(xs) + list(dys):
+                t.record_stream(side)
+        else:
+            self._wgrad_to_grouped_impl(keys, op, xs, dys, cout, inv_maps, dw_dsts, db_dsts, mode)
+            self._wg_sync_needed = self.wgrad_async
+
+    def _wgrad_to_grouped_impl(self, keys, op, xs, dys, cout, inv_maps, dw_dsts, db_dsts, mode):
+        G = len(keys)
+        x0, x_ldc = cl(xs[0])
+        d0, dy_ldc = cl(dys[0])
+        n, di, hi, wi, cin = x0.shape
+        _, do, ho, wo, _ = d0.shape
+        nsplit = self.lib.cwf_wgrad_nsplit(op, n, do, ho, wo, cin, cout)
+        slab = self.lib.cwf_wgrad_slab_floats(op, cin, cout)
+        if nsplit <= 0 or slab <= 0 or any(slab != m.numel() for m in inv_maps):
+            raise _lib.CwfError("cwf_wgrad plan failed (%d, %d)" % (nsplit, slab))
+        parts = []
+        for q in range(G):
+            assert xs[q].stride() == xs[0].stride() and dys[q].stride() == dys[0].stride() and xs[q].shape == xs[0].shape
+            pk_ = (keys[q], x0.device)
+            part = self._wg_part.get(pk_)
+            if part is None or part.numel() < nsplit * slab:
+                part = torch.empty(int(nsplit * slab), dtype=_f32, device=x0.device)
+                self._wg_part[pk_] = part
+            parts.append(part)
+        xp = (ctypes.c_void_p * G)(*[t.data_ptr() for t in xs])
+        dp = (ctypes.c_void_p * G)(*[t.data_ptr() for t in dys])
+        pp = (ctypes.c_void_p * G)(*[t.data_ptr() for t in parts])
+        used = ctypes.c_int(0)
+        self._call("cwf_wgrad_mfma_bf16_grouped", op, 1 if mode == "bf16x3" else 0, ctypes.addressof(xp), x_ldc, ctypes.addressof(dp), dy_ldc,
+                   ctypes.addressof(pp), G, n, di, hi, wi, cin, do, ho, wo, cout, ctypes.addressof(used), self._stream())
+        for q in range(G):
+            self._wg_pending.append((parts[q].data_ptr(), inv_maps[q].data_ptr(), dw_dsts[q].data_ptr(), _p(db_dsts[q]), int(slab), int(used.value)))
+
     def wgrad_flush(self, device=None):
         """One batched reduce for every layer queued by wgrad_to since the last flush (on the weight-gradient side stream when
         that is in use: it follows the queued kernels in stream order)."""

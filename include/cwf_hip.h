@@ -112,6 +112,12 @@ int cwf_conv_mfma_bf16_nb(int op, int x3,
                           const float* nb_x, int nb_ldc, const float* nb_scale, const float* nb_shift, float nb_slope,
                           int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
                           void* stream);
+/* `groups` (2 or 3) same-shape 3x3x3 stride-1 layers' weight-gradient slabs in ONE launch: group q has its own activation view
+ * h_x[q] (row pitch x_ldc), gradient view h_dy[q] (row pitch dy_ldc) and slab buffer h_partial[q] (each sized like a single layer's,
+ * cwf_wgrad_partial_floats); no prologue.  h_*: HOST arrays of device pointers.  Reduce each group like a single layer. */
+int cwf_wgrad_mfma_bf16_grouped(int op, int x3, const float* const* h_x, int x_ldc, const float* const* h_dy, int dy_ldc,
+                                float* const* h_partial, int groups,
+                                int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int* nsplit_used, void* stream);
 /* Channel-grouped 3x3x3 stride-1 conv (op = CWF_CONV3_S1; forward, or the data gradient through the transposed packed weights):
  * `groups` (2 or 3) independent convs Cin -> Cout, group q reading input channels [q*x_goff, q*x_goff + Cin) and writing output
  * channels [q*y_goff, q*y_goff + Cout) of the same voxel rows, each with its own packed weights / bias (h_wpk16, h_bias: HOST arrays

@@ -637,6 +637,10 @@ class EmulBackend:
         return dls
 
     # ------------------------------------------------------------------ K11 / misc
+    def wgrad_to_grouped(self, keys, op, xs, dys, cout, inv_maps, dw_dsts, db_dsts, prec=None, allow_async=False):
+        for q in range(len(keys)):
+            self.wgrad_to(keys[q], op, xs[q], None, None, 1.0, dys[q], cout, inv_maps[q], dw_dsts[q], db_dsts[q])
+
     def wgrad_to(self, key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec=None, allow_async=False):
         """gradient-sink form of wgrad: the result lands in (dw_dst, db_dst) directly (the HIP backend defers the reduction)"""
         shape = (cout,) + tuple(dw_dst.shape[1:]) if op != CONVT2 else tuple(dw_dst.shape)

@@ -318,6 +318,34 @@ def test_channel_grouped_conv(hip, cin, cout, size, n, G, prec):
         close(dx_all[..., q * cin:(q + 1) * cin], ref, rtol=tol, what="dgrad group %d" % q)
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("cin,cout,size,n", [(128, 32, (8, 8, 16), 2), (32, 2, (8, 8, 16), 2), (32, 8, (8, 12, 16), 1), (8, 2, (8, 12, 16), 2)])
+def test_channel_grouped_weight_gradient(hip, cin, cout, size, n, prec):
+    """cwf_wgrad_mfma_bf16_grouped: three layers' slabs from one launch (producer/consumer kernel for 128 -> 32 and 32 -> 8, the
+    generic tiled kernel for the 2-channel layers), reduced by the batched reduce, equal the per-layer weight / bias gradients."""
+    from cwf import functional as CF
+    G = 3
+    d, h, w_ = size
+    ca = (cout + 3) // 4 * 4
+    x_all = rnd(n, d, h, w_, G * cin, seed=101).to(DEV)
+    dy_all = torch.zeros(n, d, h, w_, G * ca)
+    for q in range(G):
+        dy_all[..., q * ca:q * ca + cout] = rnd(n, d, h, w_, cout, seed=111 + q)
+    dy_all = dy_all.to(DEV)
+    ws = [rnd(cout, cin, 3, 3, 3, seed=121 + q) for q in range(G)]
+    specs = [_packed(CF.ConvSpec(pk.CONV3_S1, cin, cout), w, prec) for w in ws]
+    xs = [x_all[..., q * cin:(q + 1) * cin] for q in range(G)]
+    dys = [dy_all[..., q * ca:q * ca + cout] for q in range(G)]
+    dws = [torch.full((cout, cin, 3, 3, 3), 3.0, device=DEV) for _ in range(G)]
+    dbs = [torch.full((cout,), 3.0, device=DEV) for _ in range(G)]
+    hip.wgrad_to_grouped(specs, pk.CONV3_S1, xs, dys, cout, [s_.inv_map for s_ in specs], dws, dbs, prec=prec)
+    hip.wgrad_flush(torch.device(DEV))
+    for q in range(G):
+        gw, gb = hip.wgrad(pk.CONV3_S1, xs[q], None, None, 1.0, dys[q], cout, specs[q].inv_map, True, ws[q].numel(), prec=prec)
+        close(dws[q].reshape(-1), gw.reshape(-1).cpu(), rtol=2e-6, what="dW group %d" % q)
+        close(dbs[q], gb.cpu(), rtol=2e-6, what="db group %d" % q)
+
+
 def test_head_loss_backward_into_channel_groups(hip):
     """cwf_head_loss_bwd_ex: the three maps' logit gradients written as 4-channel groups of one [N,d,h,w,12] buffer (2 values + zeroed
     padding each) equal the per-map tensors of cwf_head_loss_bwd; forward sums from the strided slices equal the contiguous ones."""
