@@ -124,6 +124,7 @@ class HipBackend:
         self._wg_part = {}                     # layer key -> persistent split-K slab buffer (wgrad_to)
         self._wg_pending = []                  # descriptor rows awaiting the batched reduce (wgrad_flush)
         self._wg_held = []                     # launches held back while wgrad_defer is set (wgrad_release)
+        self._wg_keep = []                     # operands of released launches, referenced until join_wgrad_stream
         self.wgrad_defer = False
         self._wg_tables = {}
         self.wgrad_async = False
@@ -301,6 +302,7 @@ class HipBackend:
     def join_wgrad_stream(self):
         for st in self._wg_stream.values():
             torch.cuda.current_stream(st.device).wait_stream(st)
+        self._wg_keep.clear()                  # (blocks freed now are reused in main-stream order, which follows the side stream)
 
     def wgrad(self, op, x, in_scale, in_shift, slope, dy, cout, inv_map, has_bias_map, w_numel, w_ref_shape=None, prec=None, allow_async=False):
         if self.wgrad_async and allow_async:
@@ -325,8 +327,21 @@ class HipBackend:
         instead of competing with the decoder's own HBM-bound data gradients)."""
         self.wgrad_defer = False
         held, self._wg_held = self._wg_held, []
-        for args in held:
-            self.wgrad_to(*args, allow_async=True)
+        if not held:
+            return
+        if not self.wgrad_async:
+            for args in held:
+                self.wgrad_to(*args, allow_async=True)
+            return
+        # ONE hand-over to the side stream for the whole batch (instead of an event + stream switch + four record_stream calls per
+        # launch); the operands stay referenced until the side stream is joined (join_wgrad_stream) instead of being recorded on it
+        dev = held[0][2].device
+        side = self.wgrad_stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for args in held:
+                self._wgrad_to_impl(*args)
+        self._wg_keep.extend(held)
 
     def wgrad_to(self, key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec=None, allow_async=False):
         if self.wgrad_async and allow_async and self.wgrad_defer:
