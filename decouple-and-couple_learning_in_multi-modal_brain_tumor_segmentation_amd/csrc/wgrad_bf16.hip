@@ -16,6 +16,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
+// Workgroups of the persistent weight-gradient kernels (wgrad16, wgrad_s1, pw_wgrad: 10-16 waves each, most of a CU's registers).
+// They run on the side stream BESIDE the main stream's kernels: at one workgroup per CU (256) a main-stream workgroup often finds
+// no CU with room and waits for a whole side kernel; 192 leaves a quarter of the CUs to the main stream (in the step: 99.3 -> 100.1
+// volumes/s, although an isolated launch is slower).  CWF_SIDE_WGS overrides (multiple of 8).
+static int side_wgs() { static const int v = getenv("CWF_SIDE_WGS") ? atoi(getenv("CWF_SIDE_WGS")) : 192; return v; }
+
 struct WgArgsB {
   ConvGeom g;
   const float* x; const float* in_scale; const float* in_shift; float in_slope;
@@ -1100,7 +1106,7 @@ static int launch_pw_wgrad(const WgArgsB& a, int CG, int max_slabs, int* nsplit_
   PwWgWork wk;
   wk.Vin = g.Di * g.Hi * g.Wi;
   wk.gps = wk.Vin >> 2;
-  int wps = 256 / g.N; if (wps < 1) wps = 1;               // ~256 eight-wave workgroups in all (one per CU), each inside one sample
+  int wps = side_wgs() / g.N; if (wps < 1) wps = 1;        // ~one 8/16-wave workgroup per CU in all, each inside one sample
   if (wps * g.N > max_slabs) wps = max_slabs / g.N;
   if (wps < 1) return -1;
   constexpr int PWG_WAVES = PwgCfg<NCH, NTL, NCLS>::WAVES;
@@ -1181,7 +1187,7 @@ static int wgrad_bf16_impl(int op, int x3, const float* x, int x_ldc, const floa
   if (nsplit_used) *nsplit_used = tapsplit ? wg_splits : wg_splits * 4;
   if (!groups && op == CWF_CONV3_S1 && Cin <= 16 && Cout == 16 && (dy_ldc & 3) == 0 && (((uintptr_t)dy) & 15) == 0 && (int64_t)Do * Ho * Wo >= 32768) {
     // full-resolution 16-channel layers: persistent producer/consumer kernel, one slab per workgroup (<= 256 <= generic nsplit)
-    int grid = 256; while (grid > 8 && grid > total) grid -= 8;      // multiple of 8 (XCD-aware tile map)
+    int grid = side_wgs(); while (grid > 8 && grid > total) grid -= 8;      // multiple of 8 (XCD-aware tile map)
     const size_t lds16 = (size_t)2 * (36 * W16_XW * 16 + 16 * W16_DW * 16) * sizeof(unsigned short) * (x3 ? 2 : 1);
     hipStream_t st16 = cwf_stream(stream);
     static bool at0 = false, at1 = false;
@@ -1222,7 +1228,7 @@ static int wgrad_bf16_impl(int op, int x3, const float* x, int x_ldc, const floa
     static const bool off = getenv("CWF_NO_WGRAD_S1") != nullptr;       // A/B switch (diagnostics)
     if (!off) {
       // producer / consumer kernel: ~256 eight-wave workgroups in all (one per CU), each a contiguous tile range of one (chunk, group)
-      int want1 = 256 / nblk; if (want1 < 1) want1 = 1; if (want1 > total) want1 = total;
+      int want1 = side_wgs() / nblk; if (want1 < 1) want1 = 1; if (want1 > total) want1 = total;
       const int tps1 = cdiv(total, want1), splits1 = cdiv(total, tps1);
       if (splits1 <= wg_splits) {                          // (the workspace was sized for wg_splits slabs)
         a.tiles_per_split = tps1;
