@@ -126,7 +126,8 @@ class HipBackend:
         self._wg_held = []                     # launches held back while wgrad_defer is set (wgrad_release)
         self._wg_keep = []                     # operands of released launches, referenced until join_wgrad_stream
         import os
-        self.flush_every = int(os.environ.get("CWF_FLUSH_EVERY", "10"))
+        self.flush_every_default = int(os.environ.get("CWF_FLUSH_EVERY", "10"))
+        self.flush_every = self.flush_every_default
         self.wgrad_defer = False
         self._wg_tables = {}
         self.wgrad_async = False
@@ -360,6 +361,11 @@ class HipBackend:
         else:
             self._wgrad_to_impl(key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec)
             self._wg_sync_needed = self.wgrad_async          # a main-stream producer: the side-stream reduce must wait for it
+        if len(self._wg_pending) >= self.flush_every:
+            # reduce in instalments: the LAST reduce of backward (after the stem's weight gradient) is exposed before the optimizer
+            # step -- it should carry a handful of layers, not a whole phase.  (The Trainer switches this off in hipGraph mode:
+            # the descriptor tables are keyed by their rows and must already exist when the capture runs.)
+            self.wgrad_flush(x.device)
 
     def _wgrad_to_impl(self, key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec):
         x, x_ldc = cl(x)
@@ -386,10 +392,7 @@ class HipBackend:
                        ctypes.addressof(used), self._stream())
             nsplit = used.value
         self._wg_pending.append((part.data_ptr(), inv_map.data_ptr(), dw_dst.data_ptr(), _p(db_dst), int(slab), int(nsplit)))
-        if len(self._wg_pending) >= self.flush_every and not torch.cuda.is_current_stream_capturing():
-            # reduce in instalments: the LAST reduce of backward (after the stem's weight gradient) is exposed before the optimizer
-            # step -- it should carry a handful of layers, not a whole phase
-            self.wgrad_flush(x.device)
+
 
     def wgrad_to_grouped(self, keys, op, xs, dys, cout, inv_maps, dw_dsts, db_dsts, prec=None, allow_async=False):
         """wgrad_to for G same-shape 3x3x3 stride-1 layers without prologue (channel-group views xs[q] / dys[q] of shared buffers):

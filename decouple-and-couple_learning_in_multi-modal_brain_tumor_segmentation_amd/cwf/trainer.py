@@ -125,6 +125,8 @@ class Trainer:
         self.opt.zero_grad(set_to_none=True)
         K = kernels_backend()
         K.wgrad_async = self.wgrad_async
+        if hasattr(K, "flush_every_default"):
+            K.flush_every = (1 << 30) if self.use_graph else K.flush_every_default   # (graph mode: one reduce per phase, in warm-up too)
         if hasattr(K, "wgrad_release"):
             K.wgrad_defer = self.wgrad_async and self.defer_decoder_wgrad and hasattr(self.model, "phase_callback")
         self._in_backward = True
