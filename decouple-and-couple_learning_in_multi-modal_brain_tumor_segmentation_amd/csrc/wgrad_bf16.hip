@@ -1187,7 +1187,8 @@ static int wgrad_bf16_impl(int op, int x3, const float* x, int x_ldc, const floa
   if (nsplit_used) *nsplit_used = tapsplit ? wg_splits : wg_splits * 4;
   if (!groups && op == CWF_CONV3_S1 && Cin <= 16 && Cout == 16 && (dy_ldc & 3) == 0 && (((uintptr_t)dy) & 15) == 0 && (int64_t)Do * Ho * Wo >= 32768) {
     // full-resolution 16-channel layers: persistent producer/consumer kernel, one slab per workgroup (<= 256 <= generic nsplit)
-    int grid = side_wgs(); while (grid > 8 && grid > total) grid -= 8;      // multiple of 8 (XCD-aware tile map)
+    // (the stem layer -- 4 input channels -- is the LAST kernel of backward: nothing runs beside it, it takes every CU)
+    int grid = Cin <= 4 ? 256 : side_wgs(); while (grid > 8 && grid > total) grid -= 8;      // multiple of 8 (XCD-aware tile map)
     const size_t lds16 = (size_t)2 * (36 * W16_XW * 16 + 16 * W16_DW * 16) * sizeof(unsigned short) * (x3 ? 2 : 1);
     hipStream_t st16 = cwf_stream(stream);
     static bool at0 = false, at1 = false;
