@@ -461,3 +461,41 @@ def test_rccl_phase_allreduce_path_one_rank(hip, monkeypatch):
         dist.destroy_process_group()
     assert float((g1 - g0).norm() / g0.norm()) < max(5e-5, 10 * noise)
     assert float((w1 - w0).norm() / w0.norm()) < 1e-5
+
+
+def test_grouped_head_maps_materialise_like_eval_and_ungrouped(hip, monkeypatch):
+    """The three sub-regions' heads run as channel-grouped launches; their training-mode outputs are LazyProb maps that share one
+    grouped logit buffer.  (1) Touching such a map materialises the real tensor (strided logits through upsample_softmax) and a loss
+    written against it back-propagates; (2) the fused loss over the grouped maps and its gradients equal the ungrouped path
+    (CWF_GROUPED_HEADS=0: one conv launch per region, per-map head-loss gradients)."""
+    from cwf import functional as CF
+    xc, target, edge = syn.synthetic_batch([0], (64, 64, 64))
+    with torch.no_grad():
+        _, aux = rm.forward(syn.det_state_dict(rm.param_shapes()), xc, return_aux=True)
+    forced = {k: v.to(DEV) for k, v in aux.items() if v.dtype == torch.int64}      # teacher-forced top-k, dropout off: comparable runs
+    x, target, edge = xc.to(DEV), target.to(DEV), edge.to(DEV)
+
+    def run(grouped):
+        monkeypatch.setenv("CWF_GROUPED_HEADS", "1" if grouped else "0")
+        m = _no_dropout_model(forced)
+        outs = m(x, None)
+        assert all(isinstance(v, CF.LazyProb) and (v.parent is not None) == grouped for v in outs[1].values())
+        loss = sum(_losses(outs, target, edge))
+        loss.backward()
+        g = {n: p.grad.detach().clone() for n, p in m.named_parameters() if "supervise_label" in n or "down_label" in n}
+        return m, outs, float(loss), g
+
+    m1, outs1, l1, g1 = run(True)
+    m0, outs0, l0, g0 = run(False)
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)
+    assert len(g1) == 48
+    for n in g1:
+        assert torch.allclose(g1[n], g0[n], rtol=2e-4, atol=1e-7 * float(g0[n].abs().max() + 1e-30)), n
+    # materialisation of a grouped lazy map: same values as the ungrouped one, differentiable
+    pm = outs1[1]["02"].materialize()
+    assert tuple(pm.shape) == (1, 2, 64, 64, 64) and torch.allclose(pm, outs0[1]["02"].materialize(), rtol=1e-5, atol=1e-6)
+    m2 = _no_dropout_model(forced)
+    o2 = m2(x, None)
+    (o2[3]["01"][:, 1].mean() + o2[4]["04"].sum() * 1e-6).backward()        # indexing / tensor methods materialise
+    gl = m2.mid_supervise_label.down_label_1.weight.grad            # (outputs[3] = the mid-level label heads)
+    assert gl is not None and bool(torch.isfinite(gl).all()) and float(gl.abs().sum()) > 0
