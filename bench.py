@@ -9,8 +9,10 @@ Inputs are resident in HBM before the timed region.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     -- the dominant kernel (3x3x3 conv 16->16 @128^3, cwf_conv_mfma): algorithmic FLOPs per launch / average
-                  launch duration measured here with HIP events on the launch stream, against the dense fp32 MFMA peak
+  roofline     -- the dominant kernel (3x3x3 conv 16->16 @128^3 x2, conv16s_kernel in the bf16 modes): ALGORITHMIC bytes per launch
+                  (x read once + y written once, fp32) / average launch duration measured here with HIP events on the launch stream,
+                  against the 8 TB/s HBM peak (fp32 mode: algorithmic FLOPs against the dense fp32 MFMA peak); `traffic` = HBM bytes
+                  per launch from the committed rocprofv3 --pmc summary
   cpu_baseline -- the CPU oracle (oracle/reference_model.py, kind "port") timed on this box's host cores, B=1 128^3.
   val_dice / max_rel_logit_err -- the other half of BASELINE.json's metric: WT/TC/ET Dice (tools.softmax_output_dice,
                   reference utils/tools.py:89-109) of the HIP model's argmax map against the CPU oracle's argmax map, and the
@@ -189,9 +191,11 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
-    ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph of fwd+bwd instead of launching every kernel from "
-                    "Python (host cost 1 ms instead of ~26 ms per step; currently slower end to end: the three sub-region streams "
-                    "overlap in eager mode but a captured graph serialises more)")
+    ap.add_argument("--mode", default="plan", choices=["plan", "eager", "hipgraph"],
+                    help="plan: the step is captured once and re-issued by the library as a launch list (csrc/plan.hip: one plain launch per "
+                         "node, ~2 ms of host time per step); eager: every kernel launched from Python (~14-16 ms of host time per step); "
+                         "hipgraph: the captured graph replayed with hipGraphLaunch (~44 us of host time per node on ROCm 7.2)")
+    ap.add_argument("--graph", action="store_true", help="alias of --mode hipgraph (kept for older command lines)")
     ap.add_argument("--no-wgrad-async", action="store_true", help="keep the weight gradients on the main stream (A/B)")
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
                     help="MFMA operand form of the conv family (storage and accumulation are fp32 in every mode)")
@@ -234,7 +238,8 @@ def main():
 
     torch.manual_seed(1000 + rank)                       # train_no_amp.py:85 seed, per-rank streams
     model = get_cls_wise_former(dataset="brats", _conv_repr=True, _pe_type="fixed").to(dev).train()   # random init, dropout ON
-    trainer = Trainer(model, lr=2e-4, weight_decay=1e-5, amsgrad=True, end_epoch=1000, use_graph=args.graph, wgrad_async=not args.no_wgrad_async)
+    trainer = Trainer(model, lr=2e-4, weight_decay=1e-5, amsgrad=True, end_epoch=1000, use_graph={"plan": "plan", "eager": False, "hipgraph": "hipgraph"}["hipgraph" if args.graph else args.mode],
+                      wgrad_async=not args.no_wgrad_async)
     size = (args.size,) * 3
     idx = [rank * args.batch + i for i in range(args.batch)]
     x, target, edge = syn.synthetic_batch(idx, size)
@@ -263,6 +268,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss)
+    # host cost of issuing one step, UNTHROTTLED: with the GPU idle at the start the launch queue never fills, so this is what the
+    # host spends (the figure above saturates at the GPU's step time once the host runs ahead and blocks on a full queue)
+    host_ms = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        trainer.step(x, target, edge, epoch=0)
+        host_ms.append((time.perf_counter() - t1) * 1e3)
+    torch.cuda.synchronize()
+    host_ms = sorted(host_ms)[len(host_ms) // 2]
     log("rank %d: timed %d steps in %.3f s" % (rank, args.steps, dt))
 
     if rank == 0:
@@ -281,8 +296,9 @@ def main():
                                    % ("configs[1]" if world == 1 else ("configs[2]" if world == 8 else "configs[1] per GPU, data-parallel"),
                                       world, args.batch, args.size, "" if world == 1 else " + gradient all-reduce (RCCL)"),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "precision": args.precision, "dgrad_precision": args.dgrad_precision,
-                       "wgrad_precision": args.wgrad_precision, "graph": bool(args.graph)},
-            "final_loss": round(final_loss, 5), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 2),
+                       "wgrad_precision": args.wgrad_precision, "mode": ("hipgraph" if args.graph else args.mode) if trainer._graph is not None or args.mode == "eager" else "eager (not captured)",
+                       "plan": trainer.plan_info},
+            "final_loss": round(final_loss, 5), "host_enqueue_ms_per_step": round(host_ms, 2), "host_ms_per_step_in_timed_region": round(host_dt / args.steps * 1e3, 2),
             "end_to_end": {"tflops": round(value * FLOP_PER_TRAIN_VOLUME * (args.size / 128.0) ** 3 / 1e12, 2),
                            "frac_mfma_peak_for_mode": round(value * FLOP_PER_TRAIN_VOLUME * (args.size / 128.0) ** 3 / 1e12 / world / MFMA_PEAK_TFLOPS[args.precision], 4)},
         }

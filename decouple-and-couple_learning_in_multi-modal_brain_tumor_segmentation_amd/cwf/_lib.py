@@ -98,6 +98,11 @@ SIGNATURES = {
     "cwf_argmax_dice": [P, L, L, L, P, P, P, I, L, P],
     "cwf_rng_advance": [P, P],
     "cwf_dropout_mask_rng": [P, L, F, F, P, U64, P],
+    "cwf_plan_create": [P, P],
+    "cwf_plan_info": [P, P],
+    "cwf_plan_run": [P, P, P, I, P, P],
+    "cwf_plan_destroy": [P],
+    "cwf_plan_marker": [I, P],
 }
 
 
@@ -147,6 +152,8 @@ def load():
         fn.restype = L if name in RESTYPE_INT64 else I
     lib.cwf_arch.restype = C.c_char_p
     lib.cwf_arch.argtypes = []
+    lib.cwf_plan_last_error.restype = C.c_char_p
+    lib.cwf_plan_last_error.argtypes = []
     _lib = lib
     return lib
 

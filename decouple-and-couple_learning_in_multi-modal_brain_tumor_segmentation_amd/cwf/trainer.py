@@ -6,16 +6,22 @@
 Execution modes:
   * eager (default): every kernel is launched from Python (~460 launches, ~16-21 ms of host time per step, hidden behind the GPU's
     ~23 ms); the three sub-regions share each launch (grouped kernels), weight gradients run on a side stream.
-  * graph: forward + losses + backward + gradient flattening are captured ONCE into a hipGraph (torch.cuda.graph) and replayed
-    per step.  Shapes are static (fixed patch size, per-sample top-k of fixed k), the token selection and the dropout counters live
-    on device, so nothing in the step needs the host.  Slower end to end than eager on this ROCm build.
+  * plan (use_graph=True or "plan"): forward + losses + backward + gradient reduces are captured ONCE (stream capture through
+    torch.cuda.graph; shapes are static -- fixed patch size, per-sample top-k of fixed k -- and the token selection and the dropout
+    counters live on device, so nothing in the step needs the host) and re-issued per step by the library as a plain LAUNCH LIST
+    (csrc/plan.hip: one hipModuleLaunchKernel per node on the capture's stream chains, events for the cross-stream edges; ONE
+    Python -> C call per step, or one per gradient phase when data-parallel).  Host cost ~2 ms per step instead of ~16.
+  * hipgraph (use_graph="hipgraph"): the same capture replayed with hipGraphLaunch -- slower end to end than eager on this ROCm
+    build (~44 us of host time per node); kept as the fallback for graphs the plan cannot express.
 Gradients never exist as per-parameter tensors: backward kernels write them into ONE flat buffer laid out in backward-completion
 order (cwf.optim.GradSink; the conv weight gradients through one batched split-K reduce per phase), which the fused Adam launch reads.
 Multi-GPU gradient averaging (the only data-path collective) is overlapped with backward: the model fires a callback when backward
 has passed a cut point (decoder done / everything but the encoder done, ClsWiseFormer.grad_phases); the phase's contiguous slice
 (9.8 MB, then 43 MB) is all-reduced (RCCL, summed; Adam reads g / world) on a communication stream that waits for the producing
 streams -- the three region streams and the weight-gradient side stream stay in use -- while the encoder's backward (~7 ms) runs;
-only the last 14 MB slice is exposed.  Under graph replay the collective follows the replay (4 chunks of the flat buffer).
+only the last 14 MB slice is exposed.  In plan mode the cut points are captured as marker nodes on the communication stream; the
+launch list is issued up to a marker, the phase's all-reduce is enqueued behind it, and the list continues.  Under hipGraph replay
+the collective follows the replay (4 chunks of the flat buffer).
 CWF_FORCE_COMM=1 keeps the whole collective path on at world size 1 (a one-rank RCCL group): the way to exercise and profile it on a
 one-GPU box.
 Checkpoints use the reference layout {'epoch', 'state_dict' with 'module.' prefix, 'optim_dict'} (:248-253)."""
@@ -54,12 +60,15 @@ class Trainer:
         # collectives on: more than one rank, or a one-rank group with CWF_FORCE_COMM=1 (exercises the RCCL path on a one-GPU box)
         self.comm = self.world > 1 or (dist.is_available() and dist.is_initialized() and os.environ.get("CWF_FORCE_COMM", "0") == "1")
         self.opt.grad_scale = 1.0 / self.world          # the all-reduce SUMS; Adam reads g / world (the DDP average, train_no_amp.py:133)
-        self.use_graph = use_graph
+        if use_graph not in (False, True, None, "plan", "hipgraph"):
+            raise ValueError("use_graph must be False, True, 'plan' or 'hipgraph'")
+        self.graph_mode = {True: "plan", False: None, None: None}.get(use_graph, use_graph)
+        self.use_graph = self.graph_mode is not None
         self.cuda = next(model.parameters()).is_cuda
         # weight gradients on a side stream (they are leaves of backward; the data-gradient chain is its critical path)
         self.wgrad_async = bool(wgrad_async) and self.cuda
-        # all-reduce of a phase's slice as soon as backward has passed its cut point (not under graph capture)
-        self.overlap_comm = bool(overlap_comm) and self.comm and not use_graph
+        # all-reduce of a phase's slice as soon as backward has passed its cut point (eager; plan mode through captured markers)
+        self.overlap_comm = bool(overlap_comm) and self.comm and self.graph_mode != "hipgraph"
         # HIGH priority: its own hardware-queue pool (a default-priority stream can land on the main stream's queue, see
         # cwf.kernels._priority_stream), and a collective should start the moment its slice is final
         self._comm_stream = (torch.cuda.Stream(priority=torch.cuda.Stream.priority_range()[1])
@@ -71,6 +80,8 @@ class Trainer:
         if hasattr(model, "phase_callback"):
             model.phase_callback = self._phase_done
         self._graph = None
+        self._plan = None
+        self.plan_info = None
         self._static = None
         self._eager_steps = 0
         self._graph_warmup = graph_warmup
@@ -97,7 +108,7 @@ class Trainer:
             K.wgrad_release()
             K.wgrad_defer = self.wgrad_async and self.defer_level >= 2 and k == 0
         K.wgrad_flush()
-        if self.overlap_comm and not _capturing():
+        if self.overlap_comm:
             self._allreduce_chunk(k)
 
     def _allreduce_chunk(self, k):
@@ -112,8 +123,13 @@ class Trainer:
             for st in K._wg_stream.values():
                 cs.wait_stream(st)                               # the batched slab reduce of this phase
             with torch.cuda.stream(cs):
-                self._works.append(dist.all_reduce(chunk, async_op=True))
-        else:
+                if _capturing():
+                    # plan mode: the cut point becomes a marker node behind both streams; the collective itself is enqueued on this
+                    # stream by _run_plan when the launch list reaches the marker
+                    K._call("cwf_plan_marker", int(k), K._stream())
+                else:
+                    self._works.append(dist.all_reduce(chunk, async_op=True))
+        elif not _capturing():
             self._works.append(dist.all_reduce(chunk, async_op=True))
 
     def _fwd_bwd(self, x, target, edge):
@@ -142,14 +158,16 @@ class Trainer:
             if self.wgrad_async:
                 K.join_wgrad_stream()      # weight gradients were produced on the side stream
         self.opt.gather_grads()            # parameters whose gradient came through autograd after all (none on the normal path)
-        if self.overlap_comm and not _capturing():
+        if self.overlap_comm:
             self._allreduce_chunk(len(sink.chunks) - 1)
+            if _capturing() and self._comm_stream is not None:
+                torch.cuda.current_stream().wait_stream(self._comm_stream)      # (a capture must end with its forked streams joined)
         return loss.detach(), [p.detach() for p in parts]
 
     def _finish_comm(self):
         if not self.comm:
             return
-        if self.overlap_comm and self._graph is None:
+        if self.overlap_comm and (self._graph is None or self._plan is not None):
             for w in self._works:
                 w.wait()
             self._works = []
@@ -161,11 +179,52 @@ class Trainer:
                 w.wait()
 
     def _capture(self, x, target, edge):
+        import ctypes
         self._static = (x.clone(), target.clone(), edge.clone())
-        g = torch.cuda.CUDAGraph()
+        want_plan = self.graph_mode == "plan"
+        g = torch.cuda.CUDAGraph(keep_graph=True) if want_plan else torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._static_out = self._fwd_bwd(*self._static)
         self._graph = g
+        if want_plan:
+            K = kernels_backend()
+            plan = ctypes.c_void_p()
+            rc = K.lib.cwf_plan_create(ctypes.c_void_p(g.raw_cuda_graph()), ctypes.byref(plan))
+            if rc == 0:
+                info = (ctypes.c_int * 8)()
+                K._call("cwf_plan_info", plan, info)
+                self._plan = plan
+                self.plan_info = dict(zip(("nodes", "kernels", "markers", "streams", "events", "on_stream0", "on_stream1", "on_streams2plus"), list(info)))
+            else:
+                # a node kind the launch list cannot express: replay the graph the ordinary way (collectives then follow the replay)
+                self.plan_info = {"error": int(rc), "detail": (K.lib.cwf_plan_last_error() or b"").decode()}
+                self.overlap_comm = False
+
+    def _run_plan(self):
+        import ctypes
+        K = kernels_backend()
+        nxt, mk = ctypes.c_int(0), ctypes.c_int(-1)
+        main = K._stream()
+        cs = self._comm_stream
+        cs_raw = cs.cuda_stream if cs is not None else None
+        pos = 0
+        while True:
+            K._call("cwf_plan_run", self._plan, main, cs_raw, pos, ctypes.byref(nxt), ctypes.byref(mk))
+            if mk.value < 0:
+                break
+            lo, hi = self.opt.sink.chunks[mk.value]
+            if hi > lo and self.comm:
+                with torch.cuda.stream(cs):
+                    self._works.append(dist.all_reduce(self.opt.flat_grad[lo:hi], async_op=True))
+            pos = nxt.value
+
+    def __del__(self):
+        try:
+            if self._plan is not None:
+                kernels_backend().lib.cwf_plan_destroy(self._plan)
+                self._plan = None
+        except Exception:
+            pass
 
     def step(self, x, target, edge, epoch=0):
         """One optimisation step on a rank-local batch.  Returns (loss, [five parts]) as device tensors (no host sync)."""
@@ -175,8 +234,16 @@ class Trainer:
             self._capture(x, target, edge)
         if self._graph is not None:
             sx, st, se = self._static
-            sx.copy_(x); st.copy_(target); se.copy_(edge)
-            self._graph.replay()
+            if sx.data_ptr() != x.data_ptr():
+                sx.copy_(x)
+            if st.data_ptr() != target.data_ptr():
+                st.copy_(target)
+            if se.data_ptr() != edge.data_ptr():
+                se.copy_(edge)
+            if self._plan is not None:
+                self._run_plan()
+            else:
+                self._graph.replay()
             loss, parts = self._static_out
         else:
             loss, parts = self._fwd_bwd(x, target, edge)

@@ -425,6 +425,30 @@ int cwf_stats_channel_sum(const double* stats, float* out, int N, int C, void* s
 int cwf_channel_scale(const float* x, int x_ldc, const float* s, float* y, int y_ldc, int N, int64_t V, int C, void* stream);
 int cwf_copy_strided(const float* x, int x_ldc, float* y, int y_ldc, int64_t nvox, int C, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Launch plans: the captured training step (train_no_amp.py:181-239: forward, five losses, backward, gradient reduces) re-issued
+ * as a plain launch list.  The step is static (fixed patch size, device-side top-k, device-resident dropout counters); the host
+ * captures it once with HIP stream capture and hands the hipGraph_t over.  cwf_plan_create orders the graph's nodes
+ * topologically and assigns them to streams along the capture's chains (main stream; weight-gradient side stream, low priority);
+ * cwf_plan_run issues one plain launch per node plus an event pair per cross-stream edge -- hipGraphLaunch is not used (it costs
+ * the host ~44 us per node on ROCm 7.2, more than an eager launch).  The graph must outlive the plan (argument blocks are read
+ * from its nodes).  Unsupported node kinds (host nodes, child graphs, 2-D/3-D copies) make cwf_plan_create return
+ * CWF_E_TOOLARGE; the caller then replays the graph the ordinary way.
+ * ---------------------------------------------------------------------------------------------- */
+int cwf_plan_create(void* hip_graph, void** plan_out);
+const char* cwf_plan_last_error(void);   /* which node made the last cwf_plan_create return CWF_E_TOOLARGE */
+/* info8 = {nodes, kernel nodes, markers, streams used, cross-stream events, nodes on stream 0, on stream 1, on streams 2+} */
+int cwf_plan_info(void* plan, int* info8);
+/* Issues nodes [start, ...) on main_stream (chain 0) and the plan's own side streams until the list ends or a marker has been
+ * processed; *next = position to continue from (= node count when finished), *marker_id = the marker's id or -1 when finished.
+ * A marker's dependencies are enqueued as waits on comm_stream: work the caller puts on comm_stream after the call (the
+ * data-parallel all-reduce of the gradient slice the marker closes) runs behind them.  On finish main_stream waits for the side
+ * streams.                                                                                                                       */
+int cwf_plan_run(void* plan, void* main_stream, void* comm_stream, int start, int* next, int* marker_id);
+int cwf_plan_destroy(void* plan);
+/* a no-op kernel carrying `id`: launched (under capture) on the communication stream to mark a cut point of the step */
+int cwf_plan_marker(int id, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

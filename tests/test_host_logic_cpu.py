@@ -142,3 +142,22 @@ def test_non_cubic_patch_matches_reference_fixture(emul_backend):
         assert set(m.aux[k][0].tolist()) == set(g["topk_" + k][0].tolist()), k
     with pytest.raises(ValueError):          # fewer than 128 semantic tokens: rejected, not silently truncated
         m(torch.zeros(1, 4, 32, 64, 48), None)
+
+
+def test_c_abi_library_loads_and_exports_every_declared_symbol():
+    """include/cwf_hip.h is the drop-in boundary: the built library must load (no GPU needed for that) and export every entry point
+    the header declares; the ctypes binding (cwf/_lib.py) must cover them.  No compute call is made here."""
+    import ctypes
+    import re
+    from cwf import _lib
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "cwf_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(cwf_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 88, len(declared)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, missing
+    bound = set(_lib.SIGNATURES) | {"cwf_arch", "cwf_plan_last_error"}
+    unbound = [n for n in declared if n not in bound]
+    assert not unbound, unbound
+    assert lib.cwf_version() >= 2

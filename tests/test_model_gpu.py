@@ -85,7 +85,9 @@ def test_forward_backward_vs_reference_golden(hip, tag, size, precision_mode):
     # ---- five losses
     parts = _losses(outs, target, edge)
     assert np.allclose([float(v) for v in parts], g["loss_parts"], rtol=1e-4), ([float(v) for v in parts], g["loss_parts"])
-    # ---- gradients against the float64 truth, tolerance = the fp32 reference's own noise floor (x10) or 1e-2
+    # ---- gradients against the float64 truth, tolerance = the fp32 reference's own noise floor (x10) or 1e-2 on every per-tensor norm
+    #      (all precisions; DESIGN section 3 measures 5.7e-3 worst in the bench precision); the ten full gradients elementwise: relative L2
+    #      distance 1e-2 (fp32) / 2e-2 (single-bf16 gradient operands: 2^-9 per product, random sign, on top of the norm agreement)
     sum(parts).backward()
     names, l2, noise = list(g["grad_names"]), g["grad_l2_f64"], g["grad_noise_ref32"]
     bad = []
@@ -94,7 +96,7 @@ def test_forward_backward_vs_reference_golden(hip, tag, size, precision_mode):
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
         if l2[i] > 1e-7:
             got = float(p.grad.double().norm())
-            if abs(got - l2[i]) > max(10 * noise[i], 1e-2 if precision_mode == "fp32" else 3e-2) * l2[i]:
+            if abs(got - l2[i]) > max(10 * noise[i], 1e-2) * l2[i]:
                 bad.append((n, got, float(l2[i])))
     assert not bad, bad[:10]
     for key in g.files:
@@ -103,7 +105,7 @@ def test_forward_backward_vs_reference_golden(hip, tag, size, precision_mode):
             ref = torch.from_numpy(g[key]).double()
             got = dict(m.named_parameters())[n].grad.double().cpu()
             if float(ref.norm()) > 1e-7:
-                assert float((got - ref).norm() / ref.norm()) < max(10 * noise[names.index(n)], 1e-2 if precision_mode == "fp32" else 3e-2), n
+                assert float((got - ref).norm() / ref.norm()) < max(10 * noise[names.index(n)], 1e-2 if precision_mode == "fp32" else 2e-2), n
 
 
 def test_teacher_forced_topk_and_cpu_oracle_64(hip):
@@ -284,9 +286,95 @@ def _no_dropout_model(forced):
     return m
 
 
-def test_graph_replay_matches_eager_step(hip):
-    """Trainer(use_graph=True): forward + 5 losses + backward + gradient flattening captured into ONE hipGraph -- including the three
-    region streams and the side-stream weight gradients as parallel branches -- must give the eager step's flat gradient
+@pytest.mark.parametrize("tag,size", [("64", (64, 64, 64)), ("128", (128, 128, 128))])
+def test_trainer_training_step_vs_reference_golden(hip, tag, size):
+    """The path bench.py times, end to end against the REFERENCE's values (tests/golden/model_*.npz, float64 gradients of the imported
+    reference): cwf.trainer.Trainer on the model in TRAINING mode (dropout rates zeroed, free top-k) in the bench precision -- fused
+    head -> loss (LazyProb, grouped heads), gradient sink (flat buffer written by the backward kernels, batched split-K reduce),
+    side-stream weight gradients, deferred decoder weight gradients.  (a) the five loss parts, (b) every per-parameter gradient norm,
+    (c) the ten full gradients elementwise.  Reference: train_no_amp.py:181-239."""
+    from cwf import kernels
+    from cwf.trainer import Trainer
+    g = np.load(os.path.join(GOLDEN, "model_%s.npz" % tag))
+    kernels.set_precision("bf16x3", wgrad="bf16", dgrad="bf16")
+    try:
+        m = _no_dropout_model(None)
+        assert m.training
+        tr = Trainer(m)
+        assert tr.wgrad_async
+        x, target, edge = syn.synthetic_batch([0], size)
+        x, target, edge = x.to(DEV), target.to(DEV), edge.to(DEV)
+        for rep in range(2):                       # the second step runs on cached descriptor tables / slab buffers
+            loss, parts = tr._fwd_bwd(x, target, edge)
+            torch.cuda.synchronize()
+            assert all(p.grad is None for p in m.parameters())          # every gradient went through the sink
+            assert np.allclose([float(v) for v in parts], g["loss_parts"], rtol=1e-4), ([float(v) for v in parts], g["loss_parts"])
+            assert abs(float(loss) - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+            names, l2, noise = list(g["grad_names"]), g["grad_l2_f64"], g["grad_noise_ref32"]
+            pname = {id(p): n for n, p in m.named_parameters()}
+            got = {}
+            off = 0
+            for p in tr.opt.sink.params:
+                got[pname[id(p)]] = tr.opt.flat_grad[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            assert off == tr.opt.flat_grad.numel() and len(got) == 218
+            bad = []
+            for n, gr in got.items():
+                i = names.index(n)
+                assert bool(torch.isfinite(gr).all()), n
+                if l2[i] > 1e-7:
+                    v = float(gr.double().norm())
+                    if abs(v - l2[i]) > max(10 * noise[i], 1e-2) * l2[i]:
+                        bad.append((n, v, float(l2[i])))
+            assert not bad, (rep, bad[:10])
+            for key in g.files:
+                if key.startswith("grad::"):
+                    n = key[6:]
+                    ref = torch.from_numpy(g[key]).double()
+                    if float(ref.norm()) > 1e-7:
+                        d = float((got[n].double().cpu() - ref).norm() / ref.norm())
+                        assert d < max(10 * noise[names.index(n)], 2e-2), (n, d)
+    finally:
+        kernels.set_precision("fp32")
+
+
+def test_batch_two_at_bench_shape_128(hip):
+    """The bench shape (batch 2 x 4 x 128^3, bench precision): sample 0 of the batch against the reference's B = 1 fixture of that
+    sample (1e-3 on logits / probabilities) and sample 1 against a B = 1 HIP run of it (batch > 1 = independent samples)."""
+    from cwf import kernels
+    g = np.load(os.path.join(GOLDEN, "model_128.npz"))
+    kernels.set_precision("bf16x3", wgrad="bf16", dgrad="bf16")
+    try:
+        m = _model().eval()
+        m.collect_aux = True
+        x, _, _ = syn.synthetic_batch([0, 1], (128, 128, 128))
+        with torch.no_grad():
+            both = m(x.to(DEV), None)
+            logits2 = m.aux["logits"]
+            si = torch.from_numpy(g["prob_sample_idx"]).to(DEV)
+            prob = both[0][0:1].reshape(-1)[si].cpu().numpy()
+            assert np.abs(prob - g["prob_sample"]).max() <= 1e-3 * np.abs(g["prob_sample"]).max()
+            logit = logits2[0:1].reshape(-1)[si].cpu().numpy()
+            assert np.abs(logit - g["logits_sample"]).max() / np.abs(g["logits_sample"]).max() <= 1e-3
+            one = m(x[1:2].to(DEV), None)
+            assert float((both[0][1:2] - one[0]).abs().max()) < 1e-5
+            assert float((both[2]["04"][1:2] - one[2]["04"]).abs().max()) < 1e-5
+    finally:
+        kernels.set_precision("fp32")
+
+
+def _replay(tr):
+    if tr._plan is not None:
+        tr._run_plan()
+    else:
+        tr._graph.replay()
+
+
+@pytest.mark.parametrize("mode", ["plan", "hipgraph"])
+def test_graph_replay_matches_eager_step(hip, mode):
+    """Trainer(use_graph="plan" | "hipgraph"): forward + 5 losses + backward + gradient reduces captured ONCE -- the side-stream weight
+    gradients as a parallel branch -- and re-issued as the library's launch list (csrc/plan.hip: plain launches on two streams, events
+    for the cross-stream edges) or replayed with hipGraphLaunch, must give the eager step's flat gradient
     (teacher-forced top-k, dropout off: what remains is float-atomic reduction-order noise, measured eager vs eager), on the
     capture's own inputs and on NEW inputs copied into the static buffers; with dropout ON, two replays must draw different masks
     (the generator state is advanced by a captured kernel)."""
@@ -309,15 +397,23 @@ def test_graph_replay_matches_eager_step(hip):
                 per.append(tr.opt.flat_grad.clone())
             eager.append(per)
         noise = max(float((eager[0][i] - eager[1][i]).norm() / eager[0][i].norm()) for i in (0, 1))
-        trg = Trainer(_no_dropout_model(forced), use_graph=True)
+        trg = Trainer(_no_dropout_model(forced), use_graph=mode)
         assert trg.wgrad_async
         trg._fwd_bwd(*dev(0))                               # eager warm-up (allocations, weight-pack tables)
         torch.cuda.synchronize()
         trg._capture(*dev(0))
+        if mode == "plan":
+            pi = trg.plan_info
+            assert trg._plan is not None and "error" not in pi, pi
+            # every node is a plain launch; the weight-gradient chain sits on a stream of its own
+            assert pi["kernels"] > 300 and pi["streams"] >= 2 and pi["on_stream1"] >= 20 and pi["markers"] == 0, pi
+            assert pi["on_stream0"] > 4 * (pi["on_stream1"] + pi["on_streams2plus"]), pi
+        else:
+            assert trg._plan is None
         for i in (0, 1, 0):
             for dst, src in zip(trg._static, dev(i)):
                 dst.copy_(src)
-            trg._graph.replay()
+            _replay(trg)
             torch.cuda.synchronize()
             g = trg.opt.flat_grad
             assert bool(torch.isfinite(g).all()) and float(g.abs().sum()) > 0
@@ -325,11 +421,11 @@ def test_graph_replay_matches_eager_step(hip):
             assert diff < max(5e-5, 10 * noise), (i, diff, noise)
         # dropout on: replays differ (fresh masks), and stay finite
         m = _model().train()
-        trd = Trainer(m, use_graph=True)
+        trd = Trainer(m, use_graph=mode)
         trd._fwd_bwd(*dev(0)); torch.cuda.synchronize()
         trd._capture(*dev(0))
-        trd._graph.replay(); torch.cuda.synchronize(); g1 = trd.opt.flat_grad.clone()
-        trd._graph.replay(); torch.cuda.synchronize(); g2 = trd.opt.flat_grad.clone()
+        _replay(trd); torch.cuda.synchronize(); g1 = trd.opt.flat_grad.clone()
+        _replay(trd); torch.cuda.synchronize(); g2 = trd.opt.flat_grad.clone()
         assert bool(torch.isfinite(g1).all()) and bool(torch.isfinite(g2).all())
         assert float((g1 - g2).norm() / g1.norm()) > 1e-3
     finally:
@@ -438,9 +534,9 @@ def test_rccl_phase_allreduce_path_one_rank(hip, monkeypatch):
     forced = {k: v.to(DEV) for k, v in aux.items() if v.dtype == torch.int64}
     x, target, edge = xc.to(DEV), target.to(DEV), edge.to(DEV)
 
-    def run():
-        tr = Trainer(_no_dropout_model(forced))
-        for _ in range(2):
+    def run(mode=False, steps=2):
+        tr = Trainer(_no_dropout_model(forced), use_graph=mode)
+        for _ in range(steps):
             tr.step(x, target, edge, 0)
         torch.cuda.synchronize()
         return tr, tr.opt.flat_grad.clone(), torch.cat([p.detach().reshape(-1) for p in tr.model.parameters()])
@@ -457,10 +553,17 @@ def test_rccl_phase_allreduce_path_one_rank(hip, monkeypatch):
         tr1, g1, w1 = run()
         assert tr1.comm and tr1.overlap_comm and tr1._comm_stream is not None and tr1._comm_stream.priority < 0
         assert len(tr1.opt.sink.chunks) == 3 and tr1._works == []
+        # plan mode, data-parallel: the three cut points are captured as marker nodes on the communication stream; the launch list stops
+        # at each, the phase's all-reduce is enqueued behind it, and the list continues (two eager steps, the capture, one listed step)
+        tr2, g2, w2 = run("plan", steps=4)
+        _, g0c, w0c = run(False, steps=4)
+        assert tr2._plan is not None and tr2.plan_info["markers"] == 3 and tr2.overlap_comm and tr2._works == [], tr2.plan_info
     finally:
         dist.destroy_process_group()
     assert float((g1 - g0).norm() / g0.norm()) < max(5e-5, 10 * noise)
     assert float((w1 - w0).norm() / w0.norm()) < 1e-5
+    assert float((g2 - g0c).norm() / g0c.norm()) < 1e-3
+    assert float((w2 - w0c).norm() / w0c.norm()) < 1e-5
 
 
 def test_grouped_head_maps_materialise_like_eval_and_ungrouped(hip, monkeypatch):
