@@ -25,7 +25,7 @@ namespace {
 
 __global__ void plan_marker_kernel(int id) { (void)id; }
 
-enum NodeKind { NK_KERNEL = 0, NK_MEMSET = 1, NK_MEMCPY = 2, NK_EMPTY = 3, NK_MARKER = 4 };
+enum NodeKind { NK_KERNEL = 0, NK_MEMSET = 1, NK_EMPTY = 3, NK_MARKER = 4 };
 const int MAX_STREAMS = 4;
 
 struct PlanNode {
@@ -35,7 +35,6 @@ struct PlanNode {
     hipKernelNodeParams kp;     // NK_KERNEL (kernelParams / extra point into the graph node: the graph must outlive the plan)
     hipFunction_t fn = nullptr; // resolved once (hipGetFuncBySymbol); nullptr = launch through the host symbol
     hipMemsetParams ms;         // NK_MEMSET
-    hipMemcpy3DParms mc;        // NK_MEMCPY
     std::vector<int> wait;      // plan positions (on other streams) this node waits for
     bool record = false;        // a later node on another stream waits for this one
     hipEvent_t ev = nullptr;
@@ -158,16 +157,12 @@ extern "C" int cwf_plan_create(void* graph_, void** out) {
             }
             N.kind = NK_MEMSET;
         } else if (ty == hipGraphNodeTypeMemcpy) {
-            e = hipGraphMemcpyNodeGetParams(h, &N.mc);
-            if (e != hipSuccess) { destroy(P); return (int)e; }
-            if (N.mc.srcArray || N.mc.dstArray || N.mc.extent.height > 1 || N.mc.extent.depth > 1 || N.mc.srcPos.x || N.mc.srcPos.y ||
-                N.mc.srcPos.z || N.mc.dstPos.x || N.mc.dstPos.y || N.mc.dstPos.z) {
-                snprintf(g_detail, sizeof g_detail, "memcpy node %zu: extent %zu x %zu x %zu kind %d arrays %d", i, N.mc.extent.width, N.mc.extent.height,
-                         N.mc.extent.depth, (int)N.mc.kind, (N.mc.srcArray || N.mc.dstArray) ? 1 : 0);
-                destroy(P);
-                return CWF_E_TOOLARGE;
-            }
-            N.kind = NK_MEMCPY;
+            // hipMemcpyAsync under capture makes a 1-D copy node, for which the runtime has no parameter getter (the 3-D getter
+            // returns garbage on it): refuse copy nodes altogether rather than guess.  The step this library captures has none
+            // (its copies are kernels); a graph that does is replayed by the caller with hipGraphLaunch.
+            snprintf(g_detail, sizeof g_detail, "memcpy node at position %zu (copy nodes are not supported: no 1-D parameter getter)", i);
+            destroy(P);
+            return CWF_E_TOOLARGE;
         } else if (ty == hipGraphNodeTypeEmpty) {
             N.kind = NK_EMPTY;
         } else {
@@ -328,9 +323,6 @@ extern "C" int cwf_plan_run(void* plan, void* main_stream, void* comm_stream, in
             if (N.ms.elementSize == 1) e = hipMemsetAsync(N.ms.dst, (int)N.ms.value, N.ms.width, s);
             else if (N.ms.elementSize == 2) e = hipMemsetD16Async((hipDeviceptr_t)N.ms.dst, (unsigned short)N.ms.value, N.ms.width, s);
             else e = hipMemsetD32Async((hipDeviceptr_t)N.ms.dst, (int)N.ms.value, N.ms.width, s);
-            break;
-        case NK_MEMCPY:
-            e = hipMemcpyAsync(N.mc.dstPtr.ptr, N.mc.srcPtr.ptr, N.mc.extent.width, N.mc.kind, s);
             break;
         default:
             break;

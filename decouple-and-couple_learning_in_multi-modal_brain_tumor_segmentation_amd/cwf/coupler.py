@@ -151,13 +151,22 @@ def _select(K, cfg, j0, j1, feats, q0, q1, k, bg):
     s0, s1 = K.token_scores2(feats, q0, q1)
     idx0, inv0, idx1, inv1 = K.topk_inv(s0, s1, k)
     t = feats.shape[1]
-    for g, names in enumerate(cfg.names):
-        for j, idx, inv in ((j0, idx0, inv0), (j1, idx1, inv1)):
-            if j is not None and names[j] in cfg.forced:
-                fi, fv = K.index_inv(cfg.forced[names[j]], t)
-                idx[g * bg:(g + 1) * bg] = fi
-                inv[g * bg:(g + 1) * bg] = fv
-    return idx0, inv0, idx1, inv1
+    out = []
+    for j, idx, inv in ((j0, idx0, inv0), (j1, idx1, inv1)):
+        if j is not None and any(names[j] in cfg.forced for names in cfg.names):
+            # (assembled with torch.cat -- a kernel -- rather than slice assignment: a contiguous device-to-device copy is a memcpy
+            # node under stream capture, which the launch plan of cwf.trainer does not take)
+            pi, pv = [], []
+            for g, names in enumerate(cfg.names):
+                if names[j] in cfg.forced:
+                    fi, fv = K.index_inv(cfg.forced[names[j]], t)
+                else:
+                    fi, fv = idx[g * bg:(g + 1) * bg], inv[g * bg:(g + 1) * bg]
+                pi.append(fi)
+                pv.append(fv)
+            idx, inv = torch.cat(pi, 0), torch.cat(pv, 0)
+        out += [idx, inv]
+    return tuple(out)
 
 
 class RegionCouplerFn(torch.autograd.Function):

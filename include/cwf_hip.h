@@ -432,7 +432,7 @@ int cwf_copy_strided(const float* x, int x_ldc, float* y, int y_ldc, int64_t nvo
  * topologically and assigns them to streams along the capture's chains (main stream; weight-gradient side stream, low priority);
  * cwf_plan_run issues one plain launch per node plus an event pair per cross-stream edge -- hipGraphLaunch is not used (it costs
  * the host ~44 us per node on ROCm 7.2, more than an eager launch).  The graph must outlive the plan (argument blocks are read
- * from its nodes).  Unsupported node kinds (host nodes, child graphs, 2-D/3-D copies) make cwf_plan_create return
+ * from its nodes).  Unsupported node kinds (host nodes, child graphs, memcpy nodes) make cwf_plan_create return
  * CWF_E_TOOLARGE; the caller then replays the graph the ordinary way.
  * ---------------------------------------------------------------------------------------------- */
 int cwf_plan_create(void* hip_graph, void** plan_out);

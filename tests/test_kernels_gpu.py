@@ -153,6 +153,56 @@ def test_fused_norm_backward_sums(hip, op, cin, cout, size, n, prec):
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("cin,cout,size,n", [
+    (32, 32, (16, 16, 32), 2),       # 64 tiles, two samples: the persistent workgroups' tile ranges and the per-sample statistics flush
+    (32, 32, (8, 4, 16), 3),         # 6 tiles over 3 samples: fewer tiles than workgroup slots
+    (64, 64, (8, 8, 16), 2),         # split-bf16: one 16-channel output group per workgroup (4 groups); single-bf16: two groups of 32
+    (128, 128, (4, 8, 16), 1),       # single-bf16 only takes it (the split form's weights exceed LDS: tap-table kernel)
+    (96, 96, (4, 4, 16), 2),         # the fused edge decoupler's data gradient shape (6 output tiles)
+    (32, 64, (4, 4, 32), 1),
+    (64, 16, (8, 4, 16), 1),
+])
+def test_weight_stationary_conv(hip, cin, cout, size, n, prec):
+    """convws_kernel (conv_ws.hip): the 3x3x3 stride-1 layers with >= 32 input channels whose extents are multiples of the 4x4x16
+    tile -- weights resident in LDS, persistent workgroups.  Every prologue / epilogue combination that reaches it in the model:
+    forward with InstanceNorm + LeakyReLU prologue, bias, residual, statistics (EnBlock / DeBlock conv2); plain forward into a
+    channel slice; data gradient with a residual operand and the norm-backward sums (NaaLink / in_bwd fusion)."""
+    tol = PREC_TOL[prec]
+    from cwf import functional as CF
+    d, h, w_ = size
+    op = pk.CONV3_S1
+    x = rnd(n, d, h, w_, cin, seed=31)
+    w = rnd(cout, cin, 3, 3, 3, seed=32, scale=1.0 / math.sqrt(cin * 27))
+    b = rnd(cout, seed=33, scale=0.1)
+    in_scale = rnd(n, cin, seed=34).abs() + 0.5
+    in_shift = rnd(n, cin, seed=35)
+    res = rnd(n, d, h, w_, cout, seed=37)
+    spec = _packed(CF.ConvSpec(op, cin, cout), w, prec)
+    st_ref = E.new_stats(n, cout, None)
+    y_ref = E.conv(op, x, None, b, cout, in_scale, in_shift, 0.01, res, None, st_ref, w_ref=w)
+    st = hip.new_stats(n, cout, DEV)
+    y = hip.conv(op, x.to(DEV), spec.wpk16_f, b.to(DEV), cout, in_scale.to(DEV), in_shift.to(DEV), 0.01, res.to(DEV), None, st, prec=prec)
+    close(y, y_ref, rtol=tol, what="fwd")
+    close(st, st_ref, rtol=max(1e-5, tol), what="stats")
+    # ReLU prologue, no residual, into a channel slice of a wider buffer, strided input
+    wide = torch.full((n, d, h, w_, cout + 8), 7.0, device=DEV)
+    xw = torch.zeros((n, d, h, w_, cin + 4), device=DEV); xw[..., :cin] = x.to(DEV)
+    hip.conv(op, xw[..., :cin], spec.wpk16_f, b.to(DEV), cout, in_scale.to(DEV), in_shift.to(DEV), 0.0, out=wide[..., 8:], prec=prec)
+    close(wide[..., 8:], E.conv(op, x, None, b, cout, in_scale, in_shift, 0.0, w_ref=w), rtol=tol, what="fwd into slice")
+    assert bool((wide[..., :8] == 7.0).all())
+    # data gradient with a residual (the carried skip gradient) and the norm-backward sums, against the two-pass form
+    dy = rnd(n, d, h, w_, cout, seed=38)
+    carry = rnd(n, d, h, w_, cin, seed=39)
+    dx_ref = E.conv(pk.dgrad_op(op), dy, None, None, cin, out=torch.empty(n, d, h, w_, cin), w_ref=w, fwd_op=op, residual=carry)
+    sums = hip.new_stats(n, cin, DEV)
+    xd, sc, sh = x.to(DEV), in_scale.to(DEV), in_shift.to(DEV)
+    g = hip.conv(pk.dgrad_op(op), dy.to(DEV), spec.wpk16_d, None, cin, out=torch.empty((n, d, h, w_, cin), device=DEV), residual=carry.to(DEV),
+                 prec=prec, stats=sums, nb=(xd, sc, sh, 0.01))
+    close(g, dx_ref, rtol=tol, what="dgrad + residual")
+    close(hip.in_bwd_apply(g, xd, sc, sh, 0.01, sums), hip.in_bwd(g, xd, sc, sh, 0.01).cpu(), rtol=2e-5, what="norm-backward sums")
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("op,cin,cout,size,n", [
     (pk.CONV1, 32, 16, (8, 8, 32), 2),           # DeUp conv3 (concat -> C)
     (pk.CONV1, 16, 4, (4, 4, 16), 3),            # endconv; waves span samples (stats flush / per-sample reload inside a wave)
