@@ -4,6 +4,7 @@
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgsB {
   ConvGeom g;

@@ -7,15 +7,17 @@
 // s_waitcnt / s_barrier 31 % (split-bf16 forward) to 47 % (single-bf16 data gradient) of their cycles, the matrix pipe is 46 % / 18 %
 // busy, and the weight stream (110 KB per tile in the split form) is as much L2 -> CU traffic as the activations.
 //
-// Here the weights do not move: a persistent 8-wave workgroup (one per CU) copies the packed weights of ITS 16- or 32-channel output
-// group -- all taps, all input chunks, hi and lo images -- into LDS once (<= 112 KB) and walks a contiguous range of 4x4x16 output
-// tiles.  Per (tile, chunk) iteration every wave
-//     converts + writes the halo it prefetched (fused InstanceNorm + activation prologue, bf16 hi / lo split)  -> one LDS A image,
-//     issues the global loads of the NEXT iteration (they stay in flight across the barrier and the whole MFMA phase),
-//     runs its 14 tap-pair steps: A and B fragments by ds_read_b128 at immediate offsets, v_mfma_f32_16x16x32_bf16.
-// Wave w owns M-tiles 2w, 2w+1 (rows (w/2, 2(w&1) + m) of the tile) and all NT output-channel tiles of the group.  The epilogue
-// (bias, residual, InstanceNorm statistics or norm-backward sums, stores) is the tap-table kernel's interior fast path; statistics
-// stay in registers over all tiles of a sample.
+// Here a persistent 8-wave workgroup (one per CU) owns a 32-channel output group and a contiguous range of 4x4x16 output tiles, and
+// the weights it needs sit in LDS: one 16-input-channel chunk at a time (all 27 taps, hi and lo images: 57 KB), loaded ONCE per
+// round of 2T tiles -- the loop runs chunk-outer over the round's tiles, whose accumulators persist in registers.
+// The two 4-wave halves of the workgroup ("groups", one wave per SIMD each) alternate roles step by step:
+//     step t:   one group runs the MFMA phase of a (tile, chunk) item on ITS LDS image of the halo      (matrix pipe)
+//               the other converts + writes the halo of its next item (fused InstanceNorm + activation prologue, bf16 hi / lo split)
+//               into its own image and issues the global loads of the item after that                   (VALU / LDS / memory)
+// so each SIMD always has one wave issuing MFMAs and one wave doing everything else; one workgroup barrier per step hands over.
+// A wave of a group owns M-tiles 4w .. 4w+3 (plane w of the tile) and both output-channel tiles: A and B fragments come from LDS by
+// ds_read_b128 at immediate offsets.  Epilogue (bias, residual, InstanceNorm statistics or norm-backward sums, stores) as in the
+// tap-table kernel's interior fast path; statistics stay in registers over all tiles of a sample.
 #include "conv_args.h"
 #include <cstdlib>
 #include <type_traits>
@@ -24,78 +26,109 @@
 #define WS_IH 6
 #define WS_IW 18
 #define WS_NVOX (WS_ID * WS_IH * WS_IW)      // 648 halo voxels of a 4x4x16 tile
-#define WS_SLOTS 6                           // staging slots per thread: 648 voxels x 4 channel quads / 512 threads
+#define WS_SLOTS 11                          // staging slots per thread of a group: 648 voxels x 4 channel quads / 256 threads
+#define WS_NT 2                              // output-channel tiles (of 16) per workgroup
 
-struct WsWork { int ngroups, slots, tiles, xcd_perm, diag; };   // diag: ablation bits of the DIAG build (CWF_WS_DIAG): 1 no loads, 2 no MFMA phase, 4 no epilogue, 8 no convert
+// diag: ablation bits of the DIAG build (CWF_WS_DIAG): 1 no loads, 2 no MFMA phase, 4 no epilogue, 8 no convert
+struct WsWork { int ngroups, slots, tiles, xcd_perm, diag; };
 
 __host__ __device__ constexpr int ws_tap_bytes(int t) { return (((t / 9) * WS_IH + (t / 3) % 3) * WS_IW + t % 3) * 32; }
 
-template <bool X3, int NT, bool DIAG>
+template <bool X3, bool DIAG>
 __global__ __launch_bounds__(512) void convws_kernel(const ConvArgsB a, const WsWork wk) {
+  constexpr int NT = WS_NT;
+  constexpr int T = 1;                                     // tiles per group and round (two per group do not fit the register file beside the prefetch)
   extern __shared__ float4 lds4[];
   const ConvGeom& g = a.g;
   const int nch = g.nchunks;
   char* lds = reinterpret_cast<char*>(lds4);
-  const int b_bytes = nch * 14 * NT * 1024;
+  constexpr int B_IMG = 14 * NT * 1024;                    // one chunk of one image (hi or lo)
+  constexpr int B_ALL = B_IMG * (X3 ? 2 : 1);
+  constexpr int A_IMG = WS_NVOX * 32;
+  constexpr int A_GRP = A_IMG * (X3 ? 2 : 1);
+  constexpr int NB = (B_ALL + 4095) / 4096;                // uint4 per thread of GROUP 0 for one chunk's weights
   char* Bh = lds;
-  char* Bl = lds + b_bytes;
-  char* Ah = lds + b_bytes * (X3 ? 2 : 1);
-  char* Al = Ah + WS_NVOX * 32;
-  float* red = reinterpret_cast<float*>(Ah + WS_NVOX * 32 * (X3 ? 2 : 1));
-
+  char* Bl = lds + B_IMG;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wl = wave & 3, tg = tid & 255;      // group (0 / 1), wave in group, thread in group
+  char* Ah = lds + B_ALL + grp * A_GRP;
+  char* Al = Ah + A_IMG;
+  float* red = reinterpret_cast<float*>(lds + B_ALL + 2 * A_GRP);
   const int r = lane & 15, kq = lane >> 4;
   const bool second = (kq >> 1) != 0;
 
   // ---- work: output-channel group and a contiguous range of spatial tiles (contiguous per XCD: neighbouring tiles share halo rows in L2)
-  int grp, slot;
+  int cgrp, slot;
   {
     const int b = blockIdx.x;
     if (wk.xcd_perm) {
       const int per = gridDim.x >> 3, j = b >> 3;
-      grp = j % wk.ngroups;
+      cgrp = j % wk.ngroups;
       slot = (b & 7) * (per / wk.ngroups) + j / wk.ngroups;
     } else {
-      grp = b % wk.ngroups;
+      cgrp = b % wk.ngroups;
       slot = b / wk.ngroups;
     }
   }
   const int t_begin = (int)(((int64_t)slot * wk.tiles) / wk.slots), t_end = (int)(((int64_t)(slot + 1) * wk.tiles) / wk.slots);
-  const int nt0 = grp * NT;
-
-  // ---- packed weights of this group -> LDS (hi image, lo image), lane-linear 1 KB blocks [chunk][step][j]
-  {
-    const uint4* wsrc = a.wpk + (int64_t)g.cls_wbase16[0] * 128;
-    const int nblk = nch * 14 * NT * 64;
-    for (int e = tid; e < nblk; e += 512) {
-      const int ln = e & 63, blk = e >> 6;
-      const int j = blk % NT, cs = blk / NT;
-      const uint4* p = wsrc + ((int64_t)cs * g.ntiles + nt0 + j) * 128 + ln * 2;
-      *reinterpret_cast<uint4*>(Bh + (int64_t)e * 16) = p[0];
-      if (X3) *reinterpret_cast<uint4*>(Bl + (int64_t)e * 16) = p[1];
-    }
-  }
-
-  // ---- staging slots of this thread: halo voxel v = (tid >> 2) + 128 i, channel quad q = tid & 3
-  const int q = tid & 3;
-  int loc[WS_SLOTS];                                       // idd | ih << 8 | iw << 16, or -1
-#pragma unroll
-  for (int i = 0; i < WS_SLOTS; ++i) {
-    const int v = (tid >> 2) + 128 * i;
-    const int iw = v % WS_IW, t2 = v / WS_IW;
-    loc[i] = v < WS_NVOX ? ((t2 / WS_IH) | ((t2 % WS_IH) << 8) | (iw << 16)) : -1;
-  }
+  const int nt0 = cgrp * NT;
+  const int n_rounds = (t_end - t_begin + 2 * T - 1) / (2 * T);
+  const int n_blocks = n_rounds * nch;                     // block = (round, chunk): T items per group
   const int tiles_per_n = g.tiles_d * g.tiles_h * g.tiles_w;
+  // the tile of item (round, k) of this group, or -1 (the range does not fill its last round)
+  auto item_tile = [&](int round, int k) { const int t = t_begin + round * 2 * T + 2 * k + grp; return t < t_end ? t : -1; };
+
+  // ---- packed weights of one chunk: global -> registers -> LDS, by GROUP 0 alone: it issues the loads at the head of the step in
+  // which it converts (nothing else of it is live then: the other group is in its MFMA phase with its registers full of fragments)
+  // and writes them at the block's switch point, one step later.
+  // (asm loads like the halo prefetch below: as tracked loads the 14 destination vectors were demoted to scratch memory)
+  u32x4 bpf[NB];
+  const uint4* wsrc = a.wpk + (int64_t)g.cls_wbase16[0] * 128;
+  auto b_issue = [&](int chunk) {
+    int tgo = tg;
+    asm volatile("" : "+v"(tgo));                          // (opaque: addresses are formed one by one, not hoisted as 14 register pairs)
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      int e = tgo + 256 * i;                               // uint4 index in [image][step][j][lane]
+      if (e >= B_ALL / 16) e = 0;                          // (clamped: the load itself is unconditional)
+      const int img = e / (14 * NT * 64), e2 = e % (14 * NT * 64);
+      const int ln = e2 & 63, blk = e2 >> 6;
+      const int j = blk % NT, s = blk / NT;
+      const uint4* p = wsrc + ((int64_t)(chunk * 14 + s) * g.ntiles + nt0 + j) * 128 + ln * 2 + img;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bpf[i]) : "v"(p) : "memory");
+    }
+  };
+  // `younger`: the 13 loads of the next item were issued behind the weight loads and may stay in flight
+  auto b_write = [&](bool younger) {
+    static_assert(NB == 14 || NB == 7, "operand lists below");
+    if (NB == 14) {
+      if (younger) asm volatile("s_waitcnt vmcnt(13)" : "+v"(bpf[0]), "+v"(bpf[1]), "+v"(bpf[2]), "+v"(bpf[3]), "+v"(bpf[4]), "+v"(bpf[5]), "+v"(bpf[6]), "+v"(bpf[7 % NB]), "+v"(bpf[8 % NB]), "+v"(bpf[9 % NB]), "+v"(bpf[10 % NB]), "+v"(bpf[11 % NB]), "+v"(bpf[12 % NB]), "+v"(bpf[13 % NB]) :: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(bpf[0]), "+v"(bpf[1]), "+v"(bpf[2]), "+v"(bpf[3]), "+v"(bpf[4]), "+v"(bpf[5]), "+v"(bpf[6]), "+v"(bpf[7 % NB]), "+v"(bpf[8 % NB]), "+v"(bpf[9 % NB]), "+v"(bpf[10 % NB]), "+v"(bpf[11 % NB]), "+v"(bpf[12 % NB]), "+v"(bpf[13 % NB]) :: "memory");
+    } else {
+      if (younger) asm volatile("s_waitcnt vmcnt(13)" : "+v"(bpf[0]), "+v"(bpf[1]), "+v"(bpf[2]), "+v"(bpf[3]), "+v"(bpf[4]), "+v"(bpf[5]), "+v"(bpf[6]) :: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(bpf[0]), "+v"(bpf[1]), "+v"(bpf[2]), "+v"(bpf[3]), "+v"(bpf[4]), "+v"(bpf[5]), "+v"(bpf[6]) :: "memory");
+    }
+    int wb = tg * 16;
+    asm volatile("" : "+v"(wb));
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (256 * (i + 1) <= B_ALL / 16 || tg + 256 * i < B_ALL / 16) *reinterpret_cast<u32x4*>(Bh + wb + i * 4096) = bpf[i];     // (the lo image follows the hi image)
+  };
+
+  // ---- staging slots of this thread: halo voxel v = (tg >> 2) + 64 i, channel quad q = tg & 3
+  const int q = tg & 3;
+  const int vox0 = tg >> 2;                                // slot i holds voxel vox0 + 64 i (valid below WS_NVOX: slot 10 only for vox0 < 8)
+  const int iw_0 = vox0 % WS_IW, row_0 = vox0 / WS_IW;        // (row = idd * WS_IH + ih; 64 voxels = 3 rows + 10)
   const bool plain = a.in_scale == nullptr && a.in_slope == 1.f;
 
-  // The prefetch loads are written in inline asm: hipcc waits for every load IT tracks before the first LDS read of the MFMA phase
-  // (s_waitcnt vmcnt(0) right behind the issue block -- the whole point of the prefetch lost: 99.7 us instead of 60 at 32 ch @ 64^3);
-  // loads inside asm are invisible to its counters.  Their completion is counted by hand: ONE s_waitcnt vmcnt(0) at the head of the
-  // next iteration (pf_wait, naming every destination register).  hipcc's own counted waits stay correct beside them because its
-  // loads (epilogue residual / norm-backward operands, prologue parameters) are always YOUNGER than every asm load in flight, and
-  // vector-memory operations return in order.
+  // The prefetch loads are written in inline asm: hipcc waits for every load IT tracks before it reuses a register it believes
+  // pending, which put an s_waitcnt vmcnt(0) right behind the issue block (the prefetch waited for on the spot); loads inside asm
+  // are invisible to its counters.  Their completion is counted by hand: ONE s_waitcnt vmcnt(0) in front of the convert (pf_wait,
+  // naming every destination register).  hipcc's own counted waits stay sufficient beside them: vector-memory operations return
+  // in order, so "all but my k youngest" can only wait for MORE than it assumes.
   f32x4 pf[WS_SLOTS];
+  f32x4 pf_sc, pf_sh;                                      // the item's prologue parameters (in_scale / in_shift of its sample and chunk)
   unsigned pf_inb = 0u;
   auto issue_loads = [&](int tile, int chunk) {
     const int n = tile / tiles_per_n;
@@ -106,34 +139,44 @@ __global__ __launch_bounds__(512) void convws_kernel(const ConvArgsB a, const Ws
     const float* xb = a.x + (int64_t)n * g.Di * g.Hi * g.Wi * g.x_ldc + chunk * 16;      // wave-uniform (SGPR pair)
     const unsigned ldc4 = (unsigned)g.x_ldc * 4u;
     pf_inb = 0u;
+    int iw = iw_0, row = row_0;
+    asm volatile("" : "+v"(iw), "+v"(row));                // (opaque: per-slot coordinates are recomputed here, not kept in 30+ hoisted registers)
 #pragma unroll
     for (int i = 0; i < WS_SLOTS; ++i) {
-      const int gd = id0 + (loc[i] & 255), gh = ih0 + ((loc[i] >> 8) & 255), gw = iw0 + (loc[i] >> 16);
-      const bool ok = (loc[i] >= 0) & (gd >= 0) & (gd < g.Di) & (gh >= 0) & (gh < g.Hi) & (gw >= 0) & (gw < g.Wi);
+      const int idd = (row * 43) >> 8, ih = row - idd * WS_IH;                 // row / 6 for row < 48
+      const int gd = id0 + idd, gh = ih0 + ih, gw = iw0 + iw;
+      const bool ok = (row < WS_ID * WS_IH) & ((unsigned)gd < (unsigned)g.Di) & ((unsigned)gh < (unsigned)g.Hi) & ((unsigned)gw < (unsigned)g.Wi);
+      iw += 10; row += 3;
+      if (iw >= WS_IW) { iw -= WS_IW; ++row; }
       const unsigned lin = (unsigned)((gd * g.Hi + gh) * g.Wi + gw) * ldc4 + (unsigned)q * 16u;
       const unsigned boff = ok ? lin : (unsigned)q * 16u;          // (clamped: the load itself is unconditional)
       asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pf[i]) : "v"(boff), "s"(xb) : "memory");
       pf_inb |= ok ? (1u << i) : 0u;
     }
+    // (always two loads, so that the hand-counted waits see a fixed number per item: without a prologue they read the tensor base)
+    const float* scp = a.in_scale ? a.in_scale + (int64_t)n * g.Cin + chunk * 16 : a.x;
+    const float* shp = a.in_scale ? a.in_shift + (int64_t)n * g.Cin + chunk * 16 : a.x;
+    const unsigned qo = (unsigned)q * 16u;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pf_sc) : "v"(qo), "s"(scp) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pf_sh) : "v"(qo), "s"(shp) : "memory");
   };
-  auto pf_wait = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]) :: "memory");
+  // after_epilogue: the group's MFMA phase in between ended with an epilogue, whose 32 stores per lane (4 M-tiles x 2 channel tiles x 4
+  // rows) are younger than the halo loads and need not drain here (vmcnt(0) waited ~1 us for them at every second item)
+  auto pf_wait = [&](bool after_epilogue) {
+    if (after_epilogue)
+      asm volatile("s_waitcnt vmcnt(32)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]), "+v"(pf[6]),
+                   "+v"(pf[7]), "+v"(pf[8]), "+v"(pf[9]), "+v"(pf[10]), "+v"(pf_sc), "+v"(pf_sh) :: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]), "+v"(pf[6]),
+                   "+v"(pf[7]), "+v"(pf[8]), "+v"(pf[9]), "+v"(pf[10]), "+v"(pf_sc), "+v"(pf_sh) :: "memory");
   };
-  auto convert_write = [&](int tile, int chunk) {
-    const int n = tile / tiles_per_n;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (a.in_scale) {
-      sc = *reinterpret_cast<const f32x4*>(a.in_scale + (int64_t)n * g.Cin + chunk * 16 + q * 4);
-      sh = *reinterpret_cast<const f32x4*>(a.in_shift + (int64_t)n * g.Cin + chunk * 16 + q * 4);
-    }
-    // a use on EVERY path: hipcc must consider these two loads retired here.  Left pending in its model on the path that never reads
-    // them (no prologue), it protects their destination registers with s_waitcnt vmcnt(0) in front of the MFMA phase's first LDS
-    // reads -- which in hardware also waits for the prefetch just issued.
-    asm volatile("" : "+v"(sc), "+v"(sh));
+  auto convert_write = [&](int tile, int chunk, f32x4 sc, f32x4 sh) {
     const float slope = a.in_slope;
+    int vbase = (tg >> 2) * 32 + q * 8;                    // byte offset of slot 0 in the image; slot i adds an immediate
+    asm volatile("" : "+v"(vbase));
 #pragma unroll
     for (int i = 0; i < WS_SLOTS; ++i) {
-      if (loc[i] < 0) continue;
+      if (i == WS_SLOTS - 1 && vox0 + 64 * i >= WS_NVOX) continue;
       float v0 = pf[i][0], v1 = pf[i][1], v2 = pf[i][2], v3 = pf[i][3];
       if (!plain) {
         v0 = act01(fmaf(v0, sc[0], sh[0]), slope); v1 = act01(fmaf(v1, sc[1], sh[1]), slope);
@@ -144,57 +187,52 @@ __global__ __launch_bounds__(512) void convws_kernel(const ConvArgsB a, const Ws
       else { h.x = pack_bf16(v0, v1); h.y = pack_bf16(v2, v3); l = make_uint2(0u, 0u); }
       const bool was = (pf_inb >> i) & 1u;                // zero padding applies AFTER the activation
       h.x = was ? h.x : 0u; h.y = was ? h.y : 0u; l.x = was ? l.x : 0u; l.y = was ? l.y : 0u;
-      const int vo = (((tid >> 2) + 128 * i) * 16 + q * 4) * 2;
-      *reinterpret_cast<uint2*>(Ah + vo) = h;
-      if (X3) *reinterpret_cast<uint2*>(Al + vo) = l;
+      *reinterpret_cast<uint2*>(Ah + vbase + i * (64 * 32)) = h;
+      if (X3) *reinterpret_cast<uint2*>(Al + vbase + i * (64 * 32)) = l;
     }
   };
 
   // ---- MFMA operands: lane base addresses (bytes); everything else is an immediate
-  const int a_lane = (((wave >> 1) * WS_IH + (wave & 1) * 2) * WS_IW + r) * 32 + (kq & 1) * 16;
+  const int a_lane = ((wl * WS_IH) * WS_IW + r) * 32 + (kq & 1) * 16;
   const int b_lane = lane * 16;
 
-  f32x4 acc[2][NT];
+  f32x4 acc[T][4][NT];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int k = 0; k < T; ++k)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[k][m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float s1[NT], s2[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
   int stats_n = -1;
 
-  auto flush_stats = [&]() {                               // (all threads; called at a sample boundary and at the end)
-    __syncthreads();
+  // a sample boundary inside a workgroup's tile range (at most one workgroup per output group and boundary): this wave's partial
+  // sums go out directly; the common flush at the end of the kernel goes through LDS (one atomic per channel and workgroup)
+  auto flush_stats_wave = [&]() {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       float u1 = s1[j], u2 = s2[j];
       u1 += __shfl_xor(u1, 16, 64); u1 += __shfl_xor(u1, 32, 64);
       u2 += __shfl_xor(u2, 16, 64); u2 += __shfl_xor(u2, 32, 64);
       if (kq == 0) {
-        red[((wave * NT + j) * 16 + r) * 2 + 0] = u1;
-        red[((wave * NT + j) * 16 + r) * 2 + 1] = u2;
+        const int co = (nt0 + j) * 16 + r;
+        atomic_add_f64(a.stats + ((int64_t)stats_n * g.Cout + co) * 2 + 0, (double)u1);
+        atomic_add_f64(a.stats + ((int64_t)stats_n * g.Cout + co) * 2 + 1, (double)u2);
       }
       s1[j] = 0.f; s2[j] = 0.f;
     }
-    __syncthreads();
-    if (tid < NT * 16 * 2) {
-      const int which = tid & 1, rr = (tid >> 1) & 15, jj = tid >> 5;
-      double s = 0.0;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) s += (double)red[((w * NT + jj) * 16 + rr) * 2 + which];
-      const int co = (nt0 + jj) * 16 + rr;
-      atomic_add_f64(a.stats + ((int64_t)stats_n * g.Cout + co) * 2 + which, s);
-    }
   };
 
-  auto epilogue = [&](int tile) {
+  auto epilogue = [&](int tile, auto KK) {
+    constexpr int k = decltype(KK)::value;
     const int n = tile / tiles_per_n;
     int bx = tile - n * tiles_per_n;
     const int tw = bx % g.tiles_w; bx /= g.tiles_w;
     const int th = bx % g.tiles_h, td = bx / g.tiles_h;
     if (a.stats && n != stats_n) {
-      if (stats_n >= 0) flush_stats();
+      if (stats_n >= 0) flush_stats_wave();
       stats_n = n;
     }
     float bvj[NT];
@@ -218,8 +256,8 @@ __global__ __launch_bounds__(512) void convws_kernel(const ConvArgsB a, const Ws
         }
       }
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int od = td * 4 + (wave >> 1), oh = th * 4 + (wave & 1) * 2 + m;
+      for (int m = 0; m < 4; ++m) {
+        const int od = td * 4 + wl, oh = th * 4 + m;
         const int64_t vox0 = (((int64_t)n * g.Do + od) * g.Ho + oh) * g.Wo + tw * 16;
         char* yb = reinterpret_cast<char*>(a.y + vox0 * g.y_ldc);
         const char* rb = HAS_RES ? reinterpret_cast<const char*>(a.residual + vox0 * a.r_ldc) : nullptr;
@@ -241,7 +279,7 @@ __global__ __launch_bounds__(512) void convws_kernel(const ConvArgsB a, const Ws
         for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            float v = acc[m][j][i] + bvj[j];
+            float v = acc[k][m][j][i] + bvj[j];
             if (HAS_RES) v += rv[j][i];
             *reinterpret_cast<float*>(yb + yo[i] + j * 64) = v;
             if (HAS_NB) {
@@ -249,7 +287,7 @@ __global__ __launch_bounds__(512) void convws_kernel(const ConvArgsB a, const Ws
               const float gn = v * (h > 0.f ? 1.f : a.nb_slope);
               s1[j] += gn; s2[j] = fmaf(gn, h, s2[j]);
             } else if (HAS_STATS) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
-            acc[m][j][i] = 0.f;
+            acc[k][m][j][i] = 0.f;
           }
       }
     };
@@ -259,109 +297,207 @@ __global__ __launch_bounds__(512) void convws_kernel(const ConvArgsB a, const Ws
     else            { if (a.stats) epi(F_{}, T_{}, F_{}); else epi(F_{}, F_{}, F_{}); }
   };
 
-  // ---- main loop over (tile, chunk) iterations
-  const int n_it = (t_end - t_begin) * nch;
-  if (n_it > 0 && !(DIAG && (wk.diag & 1))) issue_loads(t_begin, 0);
-  int tile = t_begin, chunk = 0;
-  for (int it = 0; it < n_it; ++it) {
-    if (!(DIAG && (wk.diag & 1))) pf_wait();
-    __syncthreads();                                       // every wave is done reading the A image (and, first time, B is in LDS)
-    if (!(DIAG && (wk.diag & 8))) convert_write(tile, chunk);
-    __syncthreads();
-    {
-      int tn = tile, cn = chunk + 1;
-      if (cn == nch) { cn = 0; ++tn; }
-      if (it + 1 < n_it && !(DIAG && (wk.diag & 1))) issue_loads(tn, cn);   // in flight across the MFMA phase and the next barrier
-    }
-    const char* bh = Bh + chunk * (14 * NT * 1024) + b_lane;
-    const char* bl = Bl + chunk * (14 * NT * 1024) + b_lane;
+  // MFMA phase of item (block, k) of this group: 14 tap-pair steps on the group's A image and the resident chunk of weights
+  auto mfma_item = [&](int block, auto KK) {
+    constexpr int k = decltype(KK)::value;
+    const int round = block / nch, chunk = block - round * nch;
+    const int tile = item_tile(round, k);
+    if (tile < 0) return;
+    const char* bh = Bh + b_lane;
+    const char* bl = Bl + b_lane;
     const char* ah0 = Ah + a_lane;
     const char* al0 = Al + a_lane;
-    if (!(DIAG && (wk.diag & 2)))
+    if (!(DIAG && (wk.diag & 2))) {
+      // Fragment reads are pipelined by hand; the scheduling barrier per step keeps hipcc from hoisting further steps' reads on top
+      // (three steps of split-bf16 fragments in flight spilled registers).  The hi fragments of step s + 1 are requested before the
+      // MFMAs of step s (two named sets); the lo fragments of step s are requested at the head of step s and first used by its
+      // ninth MFMA (one set): per accumulator the order stays hi.hi, hi.lo, lo.hi.
+      uint4 fa[2][4], fb[2][NT], fl[4], fbl[NT];
+      auto rd_hi = [&](auto S, auto P) {
+        constexpr int s = decltype(S)::value, p = decltype(P)::value;
+        constexpr int c0 = ws_tap_bytes(2 * s), c1 = ws_tap_bytes(2 * s + 1 < 27 ? 2 * s + 1 : 2 * s);   // padded tap: zero weights, valid address
+        const int to = second ? c1 : c0;
 #pragma unroll
-    for (int s = 0; s < 14; ++s) {
-      const int c0 = ws_tap_bytes(2 * s), c1 = ws_tap_bytes(2 * s + 1 < 27 ? 2 * s + 1 : 2 * s);   // padded tap: zero weights, valid address
-      const int to = second ? c1 : c0;
-      uint4 fa[2], fl[2], fb[NT], fbl[NT];
+        for (int m = 0; m < 4; ++m) fa[p][m] = *reinterpret_cast<const uint4*>(ah0 + to + m * (WS_IW * 32));
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        fa[m] = *reinterpret_cast<const uint4*>(ah0 + to + m * (WS_IW * 32));
-        if (X3) fl[m] = *reinterpret_cast<const uint4*>(al0 + to + m * (WS_IW * 32));
-      }
+        for (int j = 0; j < NT; ++j) fb[p][j] = *reinterpret_cast<const uint4*>(bh + (s * NT + j) * 1024);
+      };
+      auto rd_lo = [&](auto S) {
+        constexpr int s = decltype(S)::value;
+        constexpr int c0 = ws_tap_bytes(2 * s), c1 = ws_tap_bytes(2 * s + 1 < 27 ? 2 * s + 1 : 2 * s);
+        const int to = second ? c1 : c0;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        fb[j] = *reinterpret_cast<const uint4*>(bh + (s * NT + j) * 1024);
-        if (X3) fbl[j] = *reinterpret_cast<const uint4*>(bl + (s * NT + j) * 1024);
-      }
+        for (int m = 0; m < 4; ++m) fl[m] = *reinterpret_cast<const uint4*>(al0 + to + m * (WS_IW * 32));
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+        for (int j = 0; j < NT; ++j) fbl[j] = *reinterpret_cast<const uint4*>(bl + (s * NT + j) * 1024);
+      };
+      auto mm = [&](auto P) {
+        constexpr int p = decltype(P)::value;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[m]), __builtin_bit_cast(bf16x8, fb[j]), acc[m][j], 0, 0, 0);
-          if (X3) {
-            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[m]), __builtin_bit_cast(bf16x8, fbl[j]), acc[m][j], 0, 0, 0);
-            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fl[m]), __builtin_bit_cast(bf16x8, fb[j]), acc[m][j], 0, 0, 0);
-          }
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[k][m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[p][m]), __builtin_bit_cast(bf16x8, fb[p][j]), acc[k][m][j], 0, 0, 0);
+        if (X3) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[k][m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[p][m]), __builtin_bit_cast(bf16x8, fbl[j]), acc[k][m][j], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[k][m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fl[m]), __builtin_bit_cast(bf16x8, fb[p][j]), acc[k][m][j], 0, 0, 0);
         }
+      };
+      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+#define WS_IC(v) std::integral_constant<int, (v)>{}
+#define WS_STEP2(S0)                                                                                           \
+      if (X3) rd_lo(WS_IC(S0)); rd_hi(WS_IC((S0) + 1), I1{}); mm(I0{}); __builtin_amdgcn_sched_barrier(0);       \
+      if (X3) rd_lo(WS_IC((S0) + 1)); if ((S0) + 2 < 14) rd_hi(WS_IC((S0) + 2 < 14 ? (S0) + 2 : 13), I0{});      \
+      mm(I1{}); __builtin_amdgcn_sched_barrier(0);
+      rd_hi(I0{}, I0{});
+      WS_STEP2(0) WS_STEP2(2) WS_STEP2(4) WS_STEP2(6) WS_STEP2(8) WS_STEP2(10) WS_STEP2(12)
+#undef WS_STEP2
+#undef WS_IC
     }
-    if (chunk == nch - 1 && !(DIAG && (wk.diag & 4))) epilogue(tile);
-    if (++chunk == nch) { chunk = 0; ++tile; }
+    if (chunk == nch - 1 && !(DIAG && (wk.diag & 4))) epilogue(tile, KK);
+  };
+  // convert step of item (block, k): the halo prefetched for it -> the group's A image; then the loads of the group's next item
+  // Order of the hand-counted waits: the item's halo and prologue parameters (13 asm loads, issued at the end of the group's previous
+  // convert) are waited for first; then (group 0) the block's weights are requested; then, after the convert, the next item's 13
+  // loads: the weights are older than those, so vmcnt(13) retires them at the switch point.  No load hipcc tracks is issued here.
+  auto conv_item = [&](int block, int k, bool with_weights) -> bool {
+    const int round = block / nch, chunk = block - round * nch;
+    const int tile = item_tile(round, k);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (tile >= 0) {
+      // (the previous item of this group closed a tile, i.e. ran an epilogue, exactly when this one opens a tile)
+      if (!(DIAG && (wk.diag & 1))) pf_wait(!DIAG && block > 0 && chunk == 0);
+      sc = pf_sc; sh = pf_sh;
+    }
+    if (with_weights) b_issue(chunk);
+    if (tile >= 0 && !(DIAG && (wk.diag & 8))) convert_write(tile, chunk, sc, sh);
+    int nb = block, nk = k + 1;
+    if (nk == T) { nk = 0; ++nb; }
+    bool issued = false;
+    if (nb < n_blocks) {
+      const int nr = nb / nch, ntile = item_tile(nr, nk);
+      if (ntile >= 0 && !(DIAG && (wk.diag & 1))) { issue_loads(ntile, nb - nr * nch); issued = true; }
+    }
+    return issued;
+  };
+
+  // ---- schedule.  Group 0 converts item i at step 2i and runs its MFMA phase at step 2i + 1; group 1 lags by one step.  A block
+  // (2T steps) is one chunk of one round; its weights replace the previous block's between the block's first and second step
+  // (group 1 finishes the previous block in the first step).
+  if (n_blocks > 0 && item_tile(0, 0) >= 0 && !(DIAG && (wk.diag & 1))) issue_loads(item_tile(0, 0), 0);
+  // (the two groups run separate loops with the same barrier count: the weight registers of group 0 then have no live range through
+  // group 1's MFMA code -- written as one loop with branches, the allocator kept them through both sides and spilled)
+  using K0 = std::integral_constant<int, 0>;
+  if (grp == 0) {
+    for (int blk = 0; blk < n_blocks; ++blk) {
+      const bool younger = conv_item(blk, 0, true);        // step 0: item converted, this block's weights requested
+      __syncthreads();
+      b_write(younger);                                    // nobody reads the weights between these two barriers
+      __syncthreads();
+      mfma_item(blk, K0{});                                // step 1
+      __syncthreads();
+    }
+    __syncthreads();                                       // (group 1 drains its last item)
+  } else {
+    for (int blk = 0; blk < n_blocks; ++blk) {
+      if (blk > 0) mfma_item(blk - 1, K0{});               // step 0: the previous block's item
+      __syncthreads();
+      __syncthreads();
+      conv_item(blk, 0, false);                            // step 1
+      __syncthreads();
+    }
+    if (n_blocks > 0) mfma_item(n_blocks - 1, K0{});
+    __syncthreads();
   }
-  if (a.stats && stats_n >= 0) flush_stats();
+
+  // ---- statistics of each group's last sample: one atomic per channel, group and workgroup
+  if (a.stats) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float u1 = s1[j], u2 = s2[j];
+      u1 += __shfl_xor(u1, 16, 64); u1 += __shfl_xor(u1, 32, 64);
+      u2 += __shfl_xor(u2, 16, 64); u2 += __shfl_xor(u2, 32, 64);
+      if (kq == 0) {
+        red[((wave * NT + j) * 16 + r) * 2 + 0] = u1;
+        red[((wave * NT + j) * 16 + r) * 2 + 1] = u2;
+      }
+    }
+    int* red_n = reinterpret_cast<int*>(red + 8 * NT * 16 * 2);
+    if (lane == 0) red_n[wave] = stats_n;
+    __syncthreads();
+    if (tid < 2 * NT * 16 * 2) {
+      const int gsel = tid / (NT * 16 * 2), t2 = tid % (NT * 16 * 2);
+      const int which = t2 & 1, rr = (t2 >> 1) & 15, jj = t2 >> 5;
+      const int sn = red_n[gsel * 4];
+      if (sn >= 0) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += (double)red[(((gsel * 4 + w) * NT + jj) * 16 + rr) * 2 + which];
+        const int co = (nt0 + jj) * 16 + rr;
+        atomic_add_f64(a.stats + ((int64_t)sn * g.Cout + co) * 2 + which, s);
+      }
+    }
+  }
 }
 
 namespace {
-template <bool X3, int NT, bool DIAG>
+template <bool X3, bool DIAG>
 int launch_ws_impl(const ConvArgsB& a, const WsWork& wk, int grid, hipStream_t st) {
-  const size_t lds = (size_t)a.g.nchunks * 14 * NT * 1024 * (X3 ? 2 : 1) + (size_t)WS_NVOX * 32 * (X3 ? 2 : 1) + 8 * NT * 16 * 2 * sizeof(float);
+  const size_t lds = (size_t)14 * WS_NT * 1024 * (X3 ? 2 : 1) + (size_t)2 * WS_NVOX * 32 * (X3 ? 2 : 1) + 8 * WS_NT * 16 * 2 * sizeof(float) + 64;
   if (lds > 160 * 1024) return CWF_E_TOOLARGE;
   static bool attr_set = false;                            // (one process per GPU: set once per process)
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convws_kernel<X3, NT, DIAG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convws_kernel<X3, DIAG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((convws_kernel<X3, NT, DIAG>), dim3(grid), dim3(512), lds, st, a, wk);
+  hipLaunchKernelGGL((convws_kernel<X3, DIAG>), dim3(grid), dim3(512), lds, st, a, wk);
   CWF_LAUNCH_CHECK();
   return 0;
 }
-template <bool X3, int NT>
+template <bool X3>
 int launch_ws(const ConvArgsB& a, WsWork wk, int grid, hipStream_t st) {
   static const char* diag = getenv("CWF_WS_DIAG");          // ablation build for profiling; the product kernel has no such branches
-  if (diag) { wk.diag = atoi(diag); return launch_ws_impl<X3, NT, true>(a, wk, grid, st); }
+  if (diag) { wk.diag = atoi(diag); return launch_ws_impl<X3, true>(a, wk, grid, st); }
   wk.diag = 0;
-  return launch_ws_impl<X3, NT, false>(a, wk, grid, st);
+  return launch_ws_impl<X3, false>(a, wk, grid, st);
 }
 }  // namespace
 
-// Returns 1 and launches if the layer is one this kernel takes (3x3x3 stride 1, Cin a multiple of 16 and >= 32, Cout a multiple of 16,
-// extents multiples of the 4x4x16 tile, no per-channel output scale, weights of one output group fit LDS); 0 = not eligible (the caller
-// falls through to the tap-table kernel); < 0 / > 1 never (errors are returned through *rc).
+// Returns 1 and launches if the layer is one this kernel takes (3x3x3 stride 1, Cin a multiple of 16 and >= 32, Cout a multiple of 32,
+// extents multiples of the 4x4x16 tile, no per-channel output scale, enough tiles to occupy the chip); 0 = not eligible (the caller
+// falls through to the tap-table kernel).  The launch status is returned through *rc.
 int cwf_try_conv_ws(int op, int x3, ConvArgsB& a, hipStream_t st, int* rc) {
   static const bool off = getenv("CWF_NO_CONV_WS") != nullptr;
   const ConvGeom& g = a.g;
   if (off || op != CWF_CONV3_S1 || a.groups || a.out_scale) return 0;
-  if (g.Cin < 32 || (g.Cin & 15) || (g.Cout & 15) || g.Cout < 16) return 0;
+  if (g.Cin < 32 || (g.Cin & 15) || (g.Cout & 31)) return 0;
   if ((g.Do & 3) || (g.Ho & 3) || (g.Wo & 15)) return 0;
   if (g.x_ldc < g.Cin || (g.x_ldc & 3)) return 0;
-  const int nch = g.Cin / 16, ntiles = g.Cout / 16;
-  const int budget = 160 * 1024 - WS_NVOX * 32 * (x3 ? 2 : 1) - 2048;
-  int NT = 0;
-  if ((ntiles & 1) == 0 && nch * 14 * 2 * 1024 * (x3 ? 2 : 1) <= budget) NT = 2;
-  else if (nch * 14 * 1 * 1024 * (x3 ? 2 : 1) <= budget) NT = 1;
-  if (!NT) return 0;
   WsWork wk;
-  wk.ngroups = ntiles / NT;
+  wk.ngroups = g.Cout / 32;
   if (wk.ngroups > 32) return 0;
+  const int64_t tiles = (int64_t)g.N * (g.Do / 4) * (g.Ho / 4) * (g.Wo / 16);
+  // small layers (fewer (tile, output group) units than CUs; measured at 128 ch @ 16^3: 68 us here against 48): the tap-table kernel's
+  // many small workgroups fill the chip better
+  static const int min_units = getenv("CWF_WS_MIN_UNITS") ? atoi(getenv("CWF_WS_MIN_UNITS")) : 256;
+  if (tiles * wk.ngroups < min_units) return 0;
   // the geometry of a 4x4x16 tile (the caller built it for its own tile choice)
   int e = cwf_build_geom(a.g, op, g.N, g.Di, g.Hi, g.Wi, g.Cin, g.x_ldc, g.Do, g.Ho, g.Wo, g.Cout, g.y_ldc, 16);
   if (e) { *rc = e; return 1; }
-  wk.tiles = a.g.N * a.g.tiles_d * a.g.tiles_h * a.g.tiles_w;
+  wk.tiles = (int)tiles;
   int per = (32 / wk.ngroups) * wk.ngroups;               // workgroups per XCD, a multiple of the group count
   wk.slots = 8 * (per / wk.ngroups);
   wk.xcd_perm = 1;
-  if (wk.slots > wk.tiles) { wk.slots = wk.tiles; wk.xcd_perm = 0; }
+  if (wk.slots * 2 > wk.tiles) { wk.slots = (wk.tiles + 1) / 2; wk.xcd_perm = 0; }      // at least two tiles per workgroup (one per group)
   const int grid = wk.slots * wk.ngroups;
-  if (x3) *rc = NT == 2 ? launch_ws<true, 2>(a, wk, grid, st) : launch_ws<true, 1>(a, wk, grid, st);
-  else *rc = NT == 2 ? launch_ws<false, 2>(a, wk, grid, st) : launch_ws<false, 1>(a, wk, grid, st);
+  *rc = x3 ? launch_ws<true>(a, wk, grid, st) : launch_ws<false>(a, wk, grid, st);
   return 1;
 }
