@@ -32,12 +32,16 @@ extern "C" int cwf_stitch_windows(const float* windows, float* y, int B, void* s
 }
 
 // seg[v] = argmax_c prob[b][c][v] (first maximum, as torch.argmax) ; counts[k][0..2] += (|o & t|, |o|, |t|) for the three BraTS regions
-// k = WT (label > 0), TC (label 1 or 3), ET (label 3) of tools.softmax_output_dice.  target may be NULL (no counts).
+// k = WT (label > 0), TC (label 1 or 3), ET (label 3) of tools.softmax_output_dice and, with NC = 18, for the three classes
+// k = 3 + (c - 1), c = 1, 2, 3 of tools.softmax_mIOU_score (|o | t| = |o| + |t| - |o & t|).  target may be NULL (no counts).
+template <int NC>
 __global__ __launch_bounds__(256) void argmax_dice_kernel(const float* __restrict__ prob, int64_t sb, int64_t sc, int64_t sv, const int64_t* __restrict__ target,
                                                          int64_t* __restrict__ seg, unsigned long long* __restrict__ counts, int64_t V, int64_t total) {
-  __shared__ unsigned int red[4][9];
+  __shared__ unsigned int red[4][NC];
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned int cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned int cnt[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) cnt[k] = 0;
   if (idx < total) {
     const int64_t b = idx / V, v = idx % V;
     const float* p = prob + b * sb + v * sv;
@@ -47,23 +51,23 @@ __global__ __launch_bounds__(256) void argmax_dice_kernel(const float* __restric
     seg[idx] = best;
     if (target) {
       const int t = (int)target[idx];
-      const bool o[3] = {best > 0, best == 1 || best == 3, best == 3};
-      const bool g[3] = {t > 0, t == 1 || t == 3, t == 3};
+      const bool o[6] = {best > 0, best == 1 || best == 3, best == 3, best == 1, best == 2, best == 3};
+      const bool g[6] = {t > 0, t == 1 || t == 3, t == 3, t == 1, t == 2, t == 3};
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { cnt[k * 3] = o[k] && g[k]; cnt[k * 3 + 1] = o[k]; cnt[k * 3 + 2] = g[k]; }
+      for (int k = 0; k < NC / 3; ++k) { cnt[k * 3] = o[k] && g[k]; cnt[k * 3 + 1] = o[k]; cnt[k * 3 + 2] = g[k]; }
     }
   }
   if (!target) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
+  for (int k = 0; k < NC; ++k) {
     unsigned int s = cnt[k];
 #pragma unroll
     for (int o2 = 32; o2 > 0; o2 >>= 1) s += __shfl_xor(s, o2, 64);
     if (lane == 0) red[w][k] = s;
   }
   __syncthreads();
-  if (threadIdx.x < 9) {
+  if (threadIdx.x < NC) {
     const unsigned int s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     if (s) atomicAdd(counts + threadIdx.x, (unsigned long long)s);
   }
@@ -74,7 +78,19 @@ extern "C" int cwf_argmax_dice(const float* prob, int64_t sb, int64_t sc, int64_
                                uint64_t* counts /* [3][3], zeroed by the caller; may be NULL with target */, int B, int64_t V, void* stream) {
   if (!prob || !seg || B <= 0 || V <= 0 || (target && !counts)) return CWF_E_BADARG;
   const int64_t total = (int64_t)B * V;
-  hipLaunchKernelGGL(argmax_dice_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, cwf_stream(stream), prob, sb, sc, sv, target, seg,
+  hipLaunchKernelGGL(argmax_dice_kernel<9>, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, cwf_stream(stream), prob, sb, sc, sv, target, seg,
+                     reinterpret_cast<unsigned long long*>(counts), V, total);
+  CWF_LAUNCH_CHECK();
+  return 0;
+}
+
+// The same with the per-class counts of tools.softmax_mIOU_score (utils/tools.py:50-61; predict_simple.py reports them next to Dice):
+// counts [6][3] = WT, TC, ET, class 1, class 2, class 3, each (|o & t|, |o|, |t|).
+extern "C" int cwf_argmax_metrics(const float* prob, int64_t sb, int64_t sc, int64_t sv, const int64_t* target, int64_t* seg,
+                                  uint64_t* counts /* [6][3], zeroed by the caller */, int B, int64_t V, void* stream) {
+  if (!prob || !seg || !target || !counts || B <= 0 || V <= 0) return CWF_E_BADARG;
+  const int64_t total = (int64_t)B * V;
+  hipLaunchKernelGGL(argmax_dice_kernel<18>, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, cwf_stream(stream), prob, sb, sc, sv, target, seg,
                      reinterpret_cast<unsigned long long*>(counts), V, total);
   CWF_LAUNCH_CHECK();
   return 0;

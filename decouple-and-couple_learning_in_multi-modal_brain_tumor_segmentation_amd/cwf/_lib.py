@@ -96,6 +96,7 @@ SIGNATURES = {
     "cwf_cat3_channels": [P, P, P, P, L, I, P],
     "cwf_stitch_windows": [P, P, I, P],
     "cwf_argmax_dice": [P, L, L, L, P, P, P, I, L, P],
+    "cwf_argmax_metrics": [P, L, L, L, P, P, P, I, L, P],
     "cwf_rng_advance": [P, P],
     "cwf_dropout_mask_rng": [P, L, F, F, P, U64, P],
     "cwf_plan_create": [P, P],

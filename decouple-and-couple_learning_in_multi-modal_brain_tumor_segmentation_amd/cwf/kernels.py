@@ -1058,8 +1058,9 @@ class HipBackend:
         self._call("cwf_stitch_windows", w.data_ptr(), y.data_ptr(), nb, self._stream())
         return y
 
-    def argmax_dice(self, prob, target=None):
-        """prob [B,4,...] (any strides with one voxel stride) -> (seg int64 [B,...], [WT, TC, ET] Dice tensor or None)"""
+    def argmax_dice(self, prob, target=None, miou=False):
+        """prob [B,4,...] (any strides with one voxel stride) -> (seg int64 [B,...], [WT, TC, ET] Dice tensor or None); with miou=True
+        (target required) a third result: the [class 1, 2, 3] IoU tensor of tools.softmax_mIOU_score (utils/tools.py:50-61)"""
         b = prob.shape[0]
         sp = tuple(prob.shape[2:])
         v = 1
@@ -1076,12 +1077,19 @@ class HipBackend:
         if target is not None:
             target = target.contiguous()
             assert target.dtype == torch.int64 and tuple(target.shape) == (b,) + sp
-            counts = torch.zeros((3, 3), dtype=torch.int64, device=prob.device)
-        self._call("cwf_argmax_dice", prob.data_ptr(), sb, sc, sv, _p(target), seg.data_ptr(), _p(counts), b, v, self._stream())
+            counts = torch.zeros((6 if miou else 3, 3), dtype=torch.int64, device=prob.device)
+        if miou:
+            assert target is not None, "mIoU needs a target"
+            self._call("cwf_argmax_metrics", prob.data_ptr(), sb, sc, sv, target.data_ptr(), seg.data_ptr(), counts.data_ptr(), b, v, self._stream())
+        else:
+            self._call("cwf_argmax_dice", prob.data_ptr(), sb, sc, sv, _p(target), seg.data_ptr(), _p(counts), b, v, self._stream())
         dice = None
         if counts is not None:
             c = counts.double()
-            dice = (2 * c[:, 0] + 1e-8) / (c[:, 1] + c[:, 2] + 1e-8)          # tools.dice_score (utils/tools.py:44-47)
+            dice = (2 * c[:3, 0] + 1e-8) / (c[:3, 1] + c[:3, 2] + 1e-8)       # tools.dice_score (utils/tools.py:44-47)
+            if miou:
+                iou = (c[3:, 0] + 1e-8) / (c[3:, 1] + c[3:, 2] - c[3:, 0] + 1e-8)   # tools.mIOU (utils/tools.py:50-53): |o & t| / |o | t|
+                return seg, dice, iou
         return seg, dice
 
     # ------------------------------------------------------------------ K11 / misc

@@ -68,9 +68,10 @@ def flip_tta(x, missing_modal, forward, resoftmax=True, batch=8):
 
 
 @torch.no_grad()
-def validate_softmax(x, target, model, deterministic=True, use_TTA=False):
+def validate_softmax(x, target, model, deterministic=True, use_TTA=False, with_miou=False):
     """One subject: stitched probabilities -> label map (argmax; class 3 stands for BraTS label 4) -> [WT, TC, ET] Dice.
-    ``deterministic`` zeroes the stem dropout that the reference leaves on in eval mode."""
+    ``deterministic`` zeroes the stem dropout that the reference leaves on in eval mode.  ``with_miou`` adds the per-class
+    IoU list of tools.softmax_mIOU_score (what predict_simple.py reports next to Dice) as a fourth result."""
     model.eval()
     saved = model.Unet_list.InitConv.dropout
     if deterministic:
@@ -85,8 +86,14 @@ def validate_softmax(x, target, model, deterministic=True, use_TTA=False):
     if prob.is_cuda and prob.dtype == torch.float32 and prob.dim() == 5 and prob.shape[1] == 4:
         from cwf.kernels import backend                     # argmax + WT/TC/ET counts in one launch (cwf_argmax_dice)
         tgt = None if target is None else target[..., :155].long()
+        if with_miou and tgt is not None:
+            seg, d, iou = backend().argmax_dice(prob, tgt, miou=True)          # argmax + Dice + IoU counts, still one launch
+            return seg, prob, [d[0], d[1], d[2]], [iou[0], iou[1], iou[2]]
         seg, d = backend().argmax_dice(prob, tgt)
-        return seg, prob, (None if d is None else [d[0], d[1], d[2]])
+        res = (seg, prob, (None if d is None else [d[0], d[1], d[2]]))
+        return res + (None,) if with_miou else res
     seg = prob.argmax(1)
     dice = tools.softmax_output_dice(seg, target[..., :155]) if target is not None else None
+    if with_miou:
+        return seg, prob, dice, (tools.softmax_mIOU_score(seg, target[..., :155]) if target is not None else None)
     return seg, prob, dice

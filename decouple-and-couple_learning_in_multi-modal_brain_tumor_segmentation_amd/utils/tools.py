@@ -1,6 +1,6 @@
 """Drop-in for the hot-path part of the reference ``utils.tools``: the per-sub-region Dice / weighted-CE losses
-(tools.py:8-34,112-231) on the fused HIP loss kernels, the collective helper (:37-41) and the integer Dice metrics
-(:44-47,89-109).  ``medpy`` (Hausdorff, tools.py:5) is not required.
+(tools.py:8-34,112-231) on the fused HIP loss kernels, the collective helper (:37-41) and the integer Dice / IoU metrics
+(:44-61,89-109).  ``medpy`` (Hausdorff, tools.py:5) is not required.
 
 Label decoding happens inside the kernel: a 4-class map uses the label as class; a binary map uses
 ``(posmask >> label) & 1`` -- sub-region k -> {target == k}; edge sets E1={1,5,6,7}, E2={2,5,6,8}, E4={4,5,7,8}
@@ -55,6 +55,18 @@ def dice_score(o, t, eps=1e-8):
     num = 2 * (o * t).sum() + eps
     den = o.sum() + t.sum() + eps
     return num / den
+
+
+def mIOU(o, t, eps=1e-8):
+    """tools.mIOU (tools.py:50-53) on boolean arrays or tensors."""
+    num = (o * t).sum() + eps
+    den = (o | t).sum() + eps
+    return num / den
+
+
+def softmax_mIOU_score(output, target):
+    """tools.softmax_mIOU_score (tools.py:56-61): IoU of classes 1, 2, 3 of integer label maps (numpy or torch)."""
+    return [mIOU(o=(output == 1), t=(target == 1)), mIOU(o=(output == 2), t=(target == 2)), mIOU(o=(output == 3), t=(target == 3))]
 
 
 def softmax_output_dice(output, target):

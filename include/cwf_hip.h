@@ -388,6 +388,10 @@ int cwf_stitch_windows(const float* windows, float* y, int B, void* stream);
  * counts[k][3] += (|o & t|, |o|, |t|) of tools.softmax_output_dice's three regions k = WT, TC, ET (uint64, zeroed by the caller)   */
 int cwf_argmax_dice(const float* prob, int64_t sb, int64_t sc, int64_t sv, const int64_t* target, int64_t* seg, uint64_t* counts,
                     int B, int64_t V, void* stream);
+/* the same plus the per-class counts of tools.softmax_mIOU_score (utils/tools.py:50-61, reported by predict_simple.py): counts[6][3] =
+ * WT, TC, ET, class 1, class 2, class 3, each (|o & t|, |o|, |t|); IoU = |o & t| / (|o| + |t| - |o & t|).  target is required.      */
+int cwf_argmax_metrics(const float* prob, int64_t sb, int64_t sc, int64_t sv, const int64_t* target, int64_t* seg, uint64_t* counts,
+                       int B, int64_t V, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K11 fused Adam (amsgrad, L2 weight decay in the gradient)  torch.optim.Adam as used at train_no_amp.py:136,239

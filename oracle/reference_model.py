@@ -392,6 +392,13 @@ def softmax_output_dice(output, target, eps=1e-8):
             ds(output == 3, target == 3)]
 
 
+def softmax_miou_score(output, target, eps=1e-8):
+    """tools.softmax_mIOU_score (tools.py:50-61) on integer label maps -> IoU of classes 1, 2, 3."""
+    def iou(o, t):
+        return float(((o & t).double().sum() + eps) / ((o | t).double().sum() + eps))
+    return [iou(output == c, target == c) for c in (1, 2, 3)]
+
+
 def tailor_and_concat(x, fwd):
     """predict_overlap.tailor_and_concat (predict_overlap.py:31-58) incl. its D-axis
     stitch offset; ``fwd(window)->prob``; x [B,4,240,240,>=155]."""

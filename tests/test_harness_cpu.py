@@ -121,3 +121,21 @@ def test_fused_adam_state_reload_cpu(emul_backend):
     t2 = torch.optim.Adam(ours, lr=1e-2, weight_decay=1e-3, amsgrad=True)
     t2.load_state_dict(opt.state_dict())
     assert float(t2.state[ours[0]]["step"]) == 6.0
+
+
+def test_miou_drop_in_equals_reference_formula():
+    """utils.tools.mIOU / softmax_mIOU_score (reference utils/tools.py:50-61, used by predict_simple.py) on numpy and torch label maps
+    against the oracle restatement, incl. an absent class (eps / eps = 1, as in the reference)."""
+    import numpy as np
+    import torch
+    from oracle import reference_model as rm
+    from utils import tools
+    g = torch.Generator().manual_seed(3)
+    o = torch.randint(0, 4, (2, 9, 10, 11), generator=g)
+    t = torch.randint(0, 3, (2, 9, 10, 11), generator=g)          # class 3 absent from the target
+    want = rm.softmax_miou_score(o, t)
+    got_t = [float(v) for v in tools.softmax_mIOU_score(o, t)]
+    got_n = [float(v) for v in tools.softmax_mIOU_score(o.numpy(), t.numpy())]
+    assert np.allclose(got_n, want, rtol=0, atol=1e-9)            # numpy label maps (what predict_simple.py passes): float64
+    assert np.allclose(got_t, want, rtol=0, atol=1e-6)            # torch label maps: the reference's expression divides in float32
+    assert float(tools.mIOU(o == 7, t == 7)) == 1.0

@@ -173,6 +173,13 @@ def test_sliding_window_predictor_matches_oracle_stitching(hip):
     assert torch.equal(seg.cpu(), prob.cpu().argmax(1))
     want = tools.softmax_output_dice(prob.cpu().argmax(1), tgt)
     assert all(abs(float(a) - float(b)) < 1e-6 for a, b in zip(dice, want))      # (the torch expression divides in float32)
+    # N4: per-class IoU (tools.softmax_mIOU_score, utils/tools.py:50-61) from the same launch == the reference formula (oracle) == the host drop-in
+    seg3, _, dice3, iou3 = po.validate_softmax(x.to(DEV), tgt.to(DEV), m, with_miou=True)
+    assert torch.equal(seg3, seg) and all(abs(float(a) - float(b)) < 1e-12 for a, b in zip(dice3, dice))
+    want_iou = rm.softmax_miou_score(prob.cpu().argmax(1), tgt)
+    assert all(abs(float(a) - b) < 1e-9 for a, b in zip(iou3, want_iou)), (iou3, want_iou)
+    host_iou = tools.softmax_mIOU_score(prob.cpu().argmax(1).numpy(), tgt.numpy())
+    assert all(abs(float(a) - b) < 1e-9 for a, b in zip(host_iou, want_iou))
     seg2, d2 = hip.argmax_dice(m(x[..., :128, :128, :128].to(DEV), None)[0], None)      # channels-last view, no target
     assert d2 is None and seg2.shape == (1, 128, 128, 128)
 
