@@ -8,6 +8,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define CWF_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)
 
+// Raise a kernel's dynamic-LDS limit to the full 160 KiB, once per DEVICE (the attribute is per device; the flag used to be per
+// process, so a second device used from the same process kept the default 64 KiB limit and its launches failed).
+#define CWF_MAX_LDS_ONCE(fn)                                                                                              \
+  do {                                                                                                                    \
+    static bool done_[64] = {};                                                                                           \
+    int dev_ = 0;                                                                                                         \
+    (void)hipGetDevice(&dev_);                                                                                            \
+    if (dev_ < 0 || dev_ >= 64 || !done_[dev_]) {                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      if (dev_ >= 0 && dev_ < 64) done_[dev_] = true;                                                                     \
+    }                                                                                                                     \
+  } while (0)
+
 static inline hipStream_t cwf_stream(void* s) { return (hipStream_t)s; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -835,7 +835,7 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
 struct C16sWork { int nseg, seg_len, hsplit, ncols; };
 static int g_conv16_diag_mode = 0;                   // diagnostics (cwf_debug_conv16_mode): 1 no stores, 2 no loads, 8 no epilogue
 
-template <bool X3>
+template <bool X3, bool DIAG>
 __global__ __launch_bounds__(512) void conv16s_kernel(const ConvArgsB a, const C16sWork wk) {
   extern __shared__ float4 lds4[];
   const ConvGeom& g = a.g;
@@ -994,7 +994,7 @@ __global__ __launch_bounds__(512) void conv16s_kernel(const ConvArgsB a, const C
       const int n = sg.n;
       const int od = sg.tile_d * C16_TD + wave, oh0 = (sg.th0 + t) * C16_TH, ow0 = sg.tile_w * 16;
       if (a.stats && n != stat_n) { flush_stats(stat_n); stat_n = n; }
-      if (od < g.Do && !(a.diag_mode & 8)) {               // diag_mode 8: no epilogue (diagnostics)
+      if (od < g.Do && !(DIAG && (a.diag_mode & 8))) {     // diag_mode 8: no epilogue (DIAG build only)
         const int64_t vox0 = (((int64_t)n * g.Do + od) * g.Ho + oh0) * g.Wo + ow0;
         float* yb = a.y + vox0 * g.y_ldc;
         const float* rb = a.residual ? a.residual + vox0 * a.r_ldc : nullptr;
@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(512) void conv16s_kernel(const ConvArgsB a, const C
     // =============================================================== loader waves
     const int lt = tid - 256;
     const int q = lt & 3, c = q * 4;
-    const bool cval = c < g.Cin && !(a.diag_mode & 2);   // diag_mode 2: no loads (diagnostics)
+    const bool cval = c < g.Cin && !(DIAG && (a.diag_mode & 2));   // diag_mode 2: no loads (DIAG build only)
     const bool has_norm = a.in_scale != nullptr;
     const float slope = a.in_slope;
     const bool plain = !has_norm && slope == 1.f;
@@ -1255,14 +1255,15 @@ static int launch_conv16s(const ConvArgsB& a, hipStream_t st) {
   wk.hsplit = (g.tiles_h + wk.seg_len - 1) / wk.seg_len;
   wk.nseg = wk.ncols * wk.hsplit;
   const size_t lds = (size_t)2 * C16_ID * C16_RH * C16_IW * 32 + (X3 ? 14 * 64 * 16 : 0);   // hi + lo rings (+ lo weights)
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv16s_kernel<X3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
   int grid = 256; while (grid > 8 && grid > wk.nseg) grid -= 8;
   ConvArgsB aa = a; aa.diag = nullptr; aa.diag_mode = g_conv16_diag_mode;
-  hipLaunchKernelGGL((conv16s_kernel<X3>), dim3(grid), dim3(512), lds, st, aa, wk);
+  // the product kernel has no diagnostic branches; cwf_debug_conv16_mode (tools/) selects the ablation instantiation
+  auto go = [&](auto D) {
+    constexpr bool DG = decltype(D)::value;
+    CWF_MAX_LDS_ONCE((&conv16s_kernel<X3, DG>));
+    hipLaunchKernelGGL((conv16s_kernel<X3, DG>), dim3(grid), dim3(512), lds, st, aa, wk);
+  };
+  if (g_conv16_diag_mode) go(std::true_type{}); else go(std::false_type{});
   CWF_LAUNCH_CHECK();
   return 0;
 }
@@ -1276,11 +1277,7 @@ static int launch_conv16_impl(ConvArgsB a, hipStream_t st) {
   const ConvGeom& g = a.g;
   const int total = g.N * g.tiles_d * g.tiles_h * g.tiles_w;
   const size_t lds = (size_t)2 * C16_NVOX * 16 * sizeof(unsigned short) * (X3 ? 2 : 1) + (X3 ? 14 * 64 * 16 : 0);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv16_kernel<X3, DIAG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  CWF_MAX_LDS_ONCE((&conv16_kernel<X3, DIAG>));
   a.diag = DIAG ? g_conv16_diag : nullptr; a.diag_mode = g_conv16_diag_mode;
   int grid = 256; while (grid > 8 && grid > total) grid -= 8;   // one 8-wave workgroup per CU; multiple of 8 (XCD map)
   hipLaunchKernelGGL((conv16_kernel<X3, DIAG>), dim3(grid), dim3(512), lds, st, a, total);
@@ -1602,11 +1599,7 @@ int launch_cfg(const ConvArgsB& a, hipStream_t st) {
   const size_t lds_red = (size_t)4 * NT * 16 * 2 * sizeof(float);
   const size_t lds = lds_tile > lds_red ? lds_tile : lds_red;
   if (lds > 160 * 1024) return CWF_E_TOOLARGE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MT, NT, WM, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  CWF_MAX_LDS_ONCE((&conv_bf16_kernel<MT, NT, WM, X3>));
   dim3 grid(g.tiles_d * g.tiles_h * g.tiles_w, cdiv(g.ntiles, WN * NT), g.N * g.ncls * (a.groups ? a.groups : 1));
   hipLaunchKernelGGL((conv_bf16_kernel<MT, NT, WM, X3>), grid, dim3(256), lds, st, a);
   CWF_LAUNCH_CHECK();

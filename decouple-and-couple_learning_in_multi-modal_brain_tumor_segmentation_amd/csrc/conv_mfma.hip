@@ -274,11 +274,7 @@ int launch_cfg(const ConvArgs& a, hipStream_t st) {
   const size_t lds_red = (size_t)4 * NT * 16 * 2 * sizeof(float);
   const size_t lds = lds_tile > lds_red ? lds_tile : lds_red;
   if (lds > 160 * 1024) return CWF_E_TOOLARGE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, NT, WM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  CWF_MAX_LDS_ONCE((&conv_mfma_kernel<MT, NT, WM>));
   dim3 grid(g.tiles_d * g.tiles_h * g.tiles_w, cdiv(g.ntiles, WN * NT), g.N * g.ncls);
   hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, WM>), grid, dim3(256), lds, st, a);
   CWF_LAUNCH_CHECK();

@@ -96,19 +96,10 @@ __global__ __launch_bounds__(512) void convws_kernel(const ConvArgsB a, const Ws
       const int ln = e2 & 63, blk = e2 >> 6;
       const int j = blk % NT, s = blk / NT;
       const uint4* p = wsrc + ((int64_t)(chunk * 14 + s) * g.ntiles + nt0 + j) * 128 + ln * 2 + img;
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bpf[i]) : "v"(p) : "memory");
+      bpf[i] = *reinterpret_cast<const u32x4*>(p);
     }
   };
-  // `younger`: the 13 loads of the next item were issued behind the weight loads and may stay in flight
-  auto b_write = [&](bool younger) {
-    static_assert(NB == 14 || NB == 7, "operand lists below");
-    if (NB == 14) {
-      if (younger) asm volatile("s_waitcnt vmcnt(13)" : "+v"(bpf[0]), "+v"(bpf[1]), "+v"(bpf[2]), "+v"(bpf[3]), "+v"(bpf[4]), "+v"(bpf[5]), "+v"(bpf[6]), "+v"(bpf[7 % NB]), "+v"(bpf[8 % NB]), "+v"(bpf[9 % NB]), "+v"(bpf[10 % NB]), "+v"(bpf[11 % NB]), "+v"(bpf[12 % NB]), "+v"(bpf[13 % NB]) :: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(bpf[0]), "+v"(bpf[1]), "+v"(bpf[2]), "+v"(bpf[3]), "+v"(bpf[4]), "+v"(bpf[5]), "+v"(bpf[6]), "+v"(bpf[7 % NB]), "+v"(bpf[8 % NB]), "+v"(bpf[9 % NB]), "+v"(bpf[10 % NB]), "+v"(bpf[11 % NB]), "+v"(bpf[12 % NB]), "+v"(bpf[13 % NB]) :: "memory");
-    } else {
-      if (younger) asm volatile("s_waitcnt vmcnt(13)" : "+v"(bpf[0]), "+v"(bpf[1]), "+v"(bpf[2]), "+v"(bpf[3]), "+v"(bpf[4]), "+v"(bpf[5]), "+v"(bpf[6]) :: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(bpf[0]), "+v"(bpf[1]), "+v"(bpf[2]), "+v"(bpf[3]), "+v"(bpf[4]), "+v"(bpf[5]), "+v"(bpf[6]) :: "memory");
-    }
+  auto b_write = [&]() {
     int wb = tg * 16;
     asm volatile("" : "+v"(wb));
 #pragma unroll
@@ -150,27 +141,17 @@ __global__ __launch_bounds__(512) void convws_kernel(const ConvArgsB a, const Ws
       if (iw >= WS_IW) { iw -= WS_IW; ++row; }
       const unsigned lin = (unsigned)((gd * g.Hi + gh) * g.Wi + gw) * ldc4 + (unsigned)q * 16u;
       const unsigned boff = ok ? lin : (unsigned)q * 16u;          // (clamped: the load itself is unconditional)
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pf[i]) : "v"(boff), "s"(xb) : "memory");
+      pf[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xb) + boff);
       pf_inb |= ok ? (1u << i) : 0u;
     }
     // (always two loads, so that the hand-counted waits see a fixed number per item: without a prologue they read the tensor base)
     const float* scp = a.in_scale ? a.in_scale + (int64_t)n * g.Cin + chunk * 16 : a.x;
     const float* shp = a.in_scale ? a.in_shift + (int64_t)n * g.Cin + chunk * 16 : a.x;
     const unsigned qo = (unsigned)q * 16u;
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pf_sc) : "v"(qo), "s"(scp) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pf_sh) : "v"(qo), "s"(shp) : "memory");
+    pf_sc = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(scp) + qo);
+    pf_sh = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(shp) + qo);
   };
-  // after_epilogue: the group's MFMA phase in between ended with an epilogue, whose 32 stores per lane (4 M-tiles x 2 channel tiles x 4
-  // rows) are younger than the halo loads and need not drain here (vmcnt(0) waited ~1 us for them at every second item)
-  auto pf_wait = [&](bool after_epilogue) {
-    if (after_epilogue)
-      asm volatile("s_waitcnt vmcnt(32)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]), "+v"(pf[6]),
-                   "+v"(pf[7]), "+v"(pf[8]), "+v"(pf[9]), "+v"(pf[10]), "+v"(pf_sc), "+v"(pf_sh) :: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]), "+v"(pf[6]),
-                   "+v"(pf[7]), "+v"(pf[8]), "+v"(pf[9]), "+v"(pf[10]), "+v"(pf_sc), "+v"(pf_sh) :: "memory");
-  };
-  auto convert_write = [&](int tile, int chunk, f32x4 sc, f32x4 sh) {
+  auto convert_write = [&](int tile, int chunk, const f32x4& sc, const f32x4& sh) {
     const float slope = a.in_slope;
     int vbase = (tg >> 2) * 32 + q * 8;                    // byte offset of slot 0 in the image; slot i adds an immediate
     asm volatile("" : "+v"(vbase));
@@ -298,11 +279,11 @@ __global__ __launch_bounds__(512) void convws_kernel(const ConvArgsB a, const Ws
   };
 
   // MFMA phase of item (block, k) of this group: 14 tap-pair steps on the group's A image and the resident chunk of weights
-  auto mfma_item = [&](int block, auto KK) {
+  auto mfma_item = [&](int block, auto KK) -> bool {
     constexpr int k = decltype(KK)::value;
     const int round = block / nch, chunk = block - round * nch;
     const int tile = item_tile(round, k);
-    if (tile < 0) return;
+    if (tile < 0) return false;
     const char* bh = Bh + b_lane;
     const char* bl = Bl + b_lane;
     const char* ah0 = Ah + a_lane;
@@ -362,60 +343,78 @@ __global__ __launch_bounds__(512) void convws_kernel(const ConvArgsB a, const Ws
 #undef WS_STEP2
 #undef WS_IC
     }
-    if (chunk == nch - 1 && !(DIAG && (wk.diag & 4))) epilogue(tile, KK);
+    if (chunk == nch - 1 && !(DIAG && (wk.diag & 4))) { epilogue(tile, KK); return true; }
+    return false;
   };
   // convert step of item (block, k): the halo prefetched for it -> the group's A image; then the loads of the group's next item
-  // Order of the hand-counted waits: the item's halo and prologue parameters (13 asm loads, issued at the end of the group's previous
-  // convert) are waited for first; then (group 0) the block's weights are requested; then, after the convert, the next item's 13
-  // loads: the weights are older than those, so vmcnt(13) retires them at the switch point.  No load hipcc tracks is issued here.
-  auto conv_item = [&](int block, int k, bool with_weights) -> bool {
-    const int round = block / nch, chunk = block - round * nch;
-    const int tile = item_tile(round, k);
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (tile >= 0) {
-      // (the previous item of this group closed a tile, i.e. ran an epilogue, exactly when this one opens a tile)
-      if (!(DIAG && (wk.diag & 1))) pf_wait(!DIAG && block > 0 && chunk == 0);
-      sc = pf_sc; sh = pf_sh;
-    }
-    if (with_weights) b_issue(chunk);
-    if (tile >= 0 && !(DIAG && (wk.diag & 8))) convert_write(tile, chunk, sc, sh);
-    int nb = block, nk = k + 1;
-    if (nk == T) { nk = 0; ++nb; }
-    bool issued = false;
-    if (nb < n_blocks) {
-      const int nr = nb / nch, ntile = item_tile(nr, nk);
-      if (ntile >= 0 && !(DIAG && (wk.diag & 1))) { issue_loads(ntile, nb - nr * nch); issued = true; }
-    }
-    return issued;
-  };
-
-  // ---- schedule.  Group 0 converts item i at step 2i and runs its MFMA phase at step 2i + 1; group 1 lags by one step.  A block
-  // (2T steps) is one chunk of one round; its weights replace the previous block's between the block's first and second step
-  // (group 1 finishes the previous block in the first step).
-  if (n_blocks > 0 && item_tile(0, 0) >= 0 && !(DIAG && (wk.diag & 1))) issue_loads(item_tile(0, 0), 0);
-  // (the two groups run separate loops with the same barrier count: the weight registers of group 0 then have no live range through
-  // group 1's MFMA code -- written as one loop with branches, the allocator kept them through both sides and spilled)
+  // ---- schedule.  Block b = (round, chunk): one item per group.  Group 0 converts its item in step 0 of the block and runs its MFMA
+  // phase in step 1; group 1 converts in step 1 and runs its MFMA phase in step 0 of the NEXT block; the block's weights replace
+  // the previous block's between the two steps (written by group 0 between two barriers, while nobody reads them).
+  //
+  // Every loop iteration issues the loads of the group's NEXT item, runs the MFMA phase of the current one, and only then waits for
+  // the loads and converts: request, wait and use of the asm loads sit in ONE iteration, so their destination registers are never
+  // live across a loop back-edge.  (With the request at the end of one iteration and the wait at the head of the next, hipcc
+  // inserted register copies of the in-flight destinations at the loop boundary -- reads of data that had not landed: wrong tiles
+  // whenever the input was not already in cache.)  tools/audit_asm_loads.py checks the emitted code for such reads.
+  // The two groups run separate loops with equal barrier counts (3 per block + 1): group 0's weight registers then have no live
+  // range through group 1's MFMA code.
   using K0 = std::integral_constant<int, 0>;
-  if (grp == 0) {
-    for (int blk = 0; blk < n_blocks; ++blk) {
-      const bool younger = conv_item(blk, 0, true);        // step 0: item converted, this block's weights requested
+  const bool no_loads = DIAG && (wk.diag & 1), no_conv = DIAG && (wk.diag & 8);
+  auto do_issue = [&](int blk) {                           // the halo + prologue parameters of this group's item of block blk
+    const int round = blk / nch, tile = item_tile(round, 0);
+    if (tile >= 0 && !no_loads) issue_loads(tile, blk - round * nch);
+  };
+  auto do_convert = [&](int blk, int younger) {           // younger < 0: the loads have been waited for already
+    const int round = blk / nch, tile = item_tile(round, 0);
+    if (tile < 0) return;
+    (void)younger;
+    // (a use of the two parameter vectors on EVERY path: left pending in hipcc's model on the path that never reads them -- no
+    // prologue -- it would protect their registers later with a full s_waitcnt vmcnt(0))
+    asm volatile("" : "+v"(pf_sc), "+v"(pf_sh));
+    if (!no_conv) convert_write(tile, blk - round * nch, pf_sc, pf_sh);
+  };
+  if (n_blocks > 0) {
+    // the first item of either group: requested AND waited for before the code of the two groups parts (hipcc hoists the common
+    // request above the branch and copies the destination registers into each side's own: after the wait that is harmless; the
+    // latency of this one fetch is exposed once per launch)
+    do_issue(0);
+    if (grp == 0) {
+      b_issue(0);
+      do_convert(0, -1);
       __syncthreads();
-      b_write(younger);                                    // nobody reads the weights between these two barriers
+      b_write();
       __syncthreads();
-      mfma_item(blk, K0{});                                // step 1
+      for (int blk = 0; blk < n_blocks; ++blk) {
+        const bool more = blk + 1 < n_blocks;
+        if (more) do_issue(blk + 1);
+        const bool epi = mfma_item(blk, K0{});             // step 1 of block blk
+        __syncthreads();
+        if (more) {                                        // step 0 of block blk + 1
+          b_issue((blk + 1) % nch);
+          do_convert(blk + 1, NB + (epi ? 32 : 0));
+        }
+        __syncthreads();                                   // group 1 has finished with the weights of block blk
+        if (more) {
+          b_write();
+          __syncthreads();
+        }
+      }
+    } else {
       __syncthreads();
+      __syncthreads();
+      do_convert(0, -1);                                   // step 1 of block 0
+      for (int blk = 0; blk < n_blocks; ++blk) {
+        const bool more = blk + 1 < n_blocks;
+        __syncthreads();
+        if (more) do_issue(blk + 1);
+        const bool epi = mfma_item(blk, K0{});             // step 0 of block blk + 1
+        __syncthreads();
+        if (more) {
+          __syncthreads();
+          do_convert(blk + 1, epi ? 32 : 0);               // step 1 of block blk + 1
+        }
+      }
     }
-    __syncthreads();                                       // (group 1 drains its last item)
-  } else {
-    for (int blk = 0; blk < n_blocks; ++blk) {
-      if (blk > 0) mfma_item(blk - 1, K0{});               // step 0: the previous block's item
-      __syncthreads();
-      __syncthreads();
-      conv_item(blk, 0, false);                            // step 1
-      __syncthreads();
-    }
-    if (n_blocks > 0) mfma_item(n_blocks - 1, K0{});
-    __syncthreads();
   }
 
   // ---- statistics of each group's last sample: one atomic per channel, group and workgroup
@@ -453,11 +452,7 @@ template <bool X3, bool DIAG>
 int launch_ws_impl(const ConvArgsB& a, const WsWork& wk, int grid, hipStream_t st) {
   const size_t lds = (size_t)14 * WS_NT * 1024 * (X3 ? 2 : 1) + (size_t)2 * WS_NVOX * 32 * (X3 ? 2 : 1) + 8 * WS_NT * 16 * 2 * sizeof(float) + 64;
   if (lds > 160 * 1024) return CWF_E_TOOLARGE;
-  static bool attr_set = false;                            // (one process per GPU: set once per process)
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convws_kernel<X3, DIAG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  CWF_MAX_LDS_ONCE((&convws_kernel<X3, DIAG>));
   hipLaunchKernelGGL((convws_kernel<X3, DIAG>), dim3(grid), dim3(512), lds, st, a, wk);
   CWF_LAUNCH_CHECK();
   return 0;
@@ -471,13 +466,22 @@ int launch_ws(const ConvArgsB& a, WsWork wk, int grid, hipStream_t st) {
 }
 }  // namespace
 
+static int g_ws_min_units = getenv("CWF_WS_MIN_UNITS") ? atoi(getenv("CWF_WS_MIN_UNITS")) : 256;
+// tests / tools: lower the size threshold so that small shapes reach this kernel too (returns the previous value)
+extern "C" int cwf_debug_ws_min_units(int v) { const int old = g_ws_min_units; g_ws_min_units = v; return old; }
+// The split-bf16 (forward) instantiation is correct and tested but NOT faster than the tap-table kernel (32 ch @ 64^3: 105 us against
+// 101; 64 ch @ 32^3: 51 against 50): the product sends only single-bf16 launches (the data gradients: 62 against 74 us, 31 against
+// 34) here.  CWF_WS_X3=1 / cwf_debug_ws_x3(1) sends the split form here too (tests, experiments).
+static int g_ws_x3 = getenv("CWF_WS_X3") ? atoi(getenv("CWF_WS_X3")) : 0;
+extern "C" int cwf_debug_ws_x3(int v) { const int old = g_ws_x3; g_ws_x3 = v; return old; }
+
 // Returns 1 and launches if the layer is one this kernel takes (3x3x3 stride 1, Cin a multiple of 16 and >= 32, Cout a multiple of 32,
 // extents multiples of the 4x4x16 tile, no per-channel output scale, enough tiles to occupy the chip); 0 = not eligible (the caller
 // falls through to the tap-table kernel).  The launch status is returned through *rc.
 int cwf_try_conv_ws(int op, int x3, ConvArgsB& a, hipStream_t st, int* rc) {
   static const bool off = getenv("CWF_NO_CONV_WS") != nullptr;
   const ConvGeom& g = a.g;
-  if (off || op != CWF_CONV3_S1 || a.groups || a.out_scale) return 0;
+  if (off || op != CWF_CONV3_S1 || a.groups || a.out_scale || (x3 && !g_ws_x3)) return 0;
   if (g.Cin < 32 || (g.Cin & 15) || (g.Cout & 31)) return 0;
   if ((g.Do & 3) || (g.Ho & 3) || (g.Wo & 15)) return 0;
   if (g.x_ldc < g.Cin || (g.x_ldc & 3)) return 0;
@@ -487,8 +491,7 @@ int cwf_try_conv_ws(int op, int x3, ConvArgsB& a, hipStream_t st, int* rc) {
   const int64_t tiles = (int64_t)g.N * (g.Do / 4) * (g.Ho / 4) * (g.Wo / 16);
   // small layers (fewer (tile, output group) units than CUs; measured at 128 ch @ 16^3: 68 us here against 48): the tap-table kernel's
   // many small workgroups fill the chip better
-  static const int min_units = getenv("CWF_WS_MIN_UNITS") ? atoi(getenv("CWF_WS_MIN_UNITS")) : 256;
-  if (tiles * wk.ngroups < min_units) return 0;
+  if (tiles * wk.ngroups < g_ws_min_units) return 0;
   // the geometry of a 4x4x16 tile (the caller built it for its own tile choice)
   int e = cwf_build_geom(a.g, op, g.N, g.Di, g.Hi, g.Wi, g.Cin, g.x_ldc, g.Do, g.Ho, g.Wo, g.Cout, g.y_ldc, 16);
   if (e) { *rc = e; return 1; }

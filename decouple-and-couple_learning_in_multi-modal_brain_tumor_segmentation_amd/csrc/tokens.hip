@@ -225,8 +225,7 @@ extern "C" int cwf_topk(const float* score, int32_t* index, int B, int T, int k,
   if (!score || !index || B <= 0 || T <= 0 || k <= 0 || k > T) return CWF_E_BADARG;
   int P = 2; while (P < T) P <<= 1;
   if (P > 16384) return CWF_E_TOOLARGE;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  CWF_MAX_LDS_ONCE((&topk_kernel));
   hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), (size_t)P * 8, cwf_stream(stream), score, index, T, k, P);
   CWF_LAUNCH_CHECK();
   return 0;

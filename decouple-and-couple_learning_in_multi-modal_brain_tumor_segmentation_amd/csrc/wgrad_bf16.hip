@@ -1191,12 +1191,11 @@ static int wgrad_bf16_impl(int op, int x3, const float* x, int x_ldc, const floa
     int grid = Cin <= 4 ? 256 : side_wgs(); while (grid > 8 && grid > total) grid -= 8;      // multiple of 8 (XCD-aware tile map)
     const size_t lds16 = (size_t)2 * (36 * W16_XW * 16 + 16 * W16_DW * 16) * sizeof(unsigned short) * (x3 ? 2 : 1);
     hipStream_t st16 = cwf_stream(stream);
-    static bool at0 = false, at1 = false;
     if (x3) {
-      if (!at1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at1 = true; }
+      CWF_MAX_LDS_ONCE((&wgrad16_kernel<true>));
       hipLaunchKernelGGL((wgrad16_kernel<true>), dim3(grid), dim3(256 + 64 * W16_LW), lds16, st16, a, total);
     } else {
-      if (!at0) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); at0 = true; }
+      CWF_MAX_LDS_ONCE((&wgrad16_kernel<false>));
       hipLaunchKernelGGL((wgrad16_kernel<false>), dim3(grid), dim3(256 + 64 * W16_LW), lds16, st16, a, total);
     }
     CWF_LAUNCH_CHECK();
@@ -1237,12 +1236,8 @@ static int wgrad_bf16_impl(int op, int x3, const float* x, int x_ldc, const floa
         const size_t lds1 = (size_t)2 * (36 * 20 * 16 + 16 * (CG == 1 ? 20 : 16) * CG * 16 + (16 / 2 + 1) * (CG == 2 ? 16 : 0)) * sizeof(unsigned short);
         dim3 grid1(splits1, nchunks * ngroups, groups ? groups : 1);
         hipStream_t st1 = cwf_stream(stream);
-        static bool attr1 = false;
-        if (!attr1) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_s1_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_s1_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          attr1 = true;
-        }
+        CWF_MAX_LDS_ONCE((&wgrad_s1_kernel<1>));
+        CWF_MAX_LDS_ONCE((&wgrad_s1_kernel<2>));
         if (CG == 1) hipLaunchKernelGGL((wgrad_s1_kernel<1>), grid1, dim3(256 + 64 * WS1_LW), lds1, st1, a);
         else hipLaunchKernelGGL((wgrad_s1_kernel<2>), grid1, dim3(256 + 64 * WS1_LW), lds1, st1, a);
         CWF_LAUNCH_CHECK();
@@ -1256,8 +1251,7 @@ static int wgrad_bf16_impl(int op, int x3, const float* x, int x_ldc, const floa
   if (lds > 160 * 1024) return CWF_E_TOOLARGE;
   dim3 grid(wg_splits, nchunks * ngroups, gz);
   hipStream_t st = cwf_stream(stream);
-#define CWF_WG(tpw, ntw, ts, xx) do { static bool attr = false; \
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<tpw, ntw, ts, xx>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+#define CWF_WG(tpw, ntw, ts, xx) do { CWF_MAX_LDS_ONCE((&wgrad_bf16_kernel<tpw, ntw, ts, xx>)); \
     hipLaunchKernelGGL((wgrad_bf16_kernel<tpw, ntw, ts, xx>), grid, dim3(256), lds, st, a); } while (0)
 #define CWF_WGX(tpw, ntw, ts) do { if (x3) CWF_WG(tpw, ntw, ts, true); else CWF_WG(tpw, ntw, ts, false); } while (0)
   if (tapsplit) { if (CG == 1) CWF_WGX(7, 1, true); else CWF_WGX(7, 2, true); }

@@ -273,8 +273,7 @@ extern "C" int cwf_wgrad_mfma(int op, const float* x, int x_ldc, const float* in
   if (lds > 160 * 1024) return CWF_E_TOOLARGE;
   dim3 grid(p.wg_splits, p.nchunks * p.ngroups, p.ncls);
   hipStream_t st = cwf_stream(stream);
-#define CWF_WG(tpw, ntw, ts) do { static bool attr = false; \
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<tpw, ntw, ts>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+#define CWF_WG(tpw, ntw, ts) do { CWF_MAX_LDS_ONCE((&wgrad_mfma_kernel<tpw, ntw, ts>)); \
     hipLaunchKernelGGL((wgrad_mfma_kernel<tpw, ntw, ts>), grid, dim3(256), lds, st, a); } while (0)
   if (p.tapsplit) { if (p.CG == 1) CWF_WG(7, 1, true); else CWF_WG(7, 2, true); }
   else { if (p.CG == 1) CWF_WG(2, 1, false); else if (p.CG == 2) CWF_WG(2, 2, false); else CWF_WG(2, 4, false); }

@@ -4,6 +4,7 @@
                      (ClsWiseTransformer.py:41-55) -> row scatter + gate (cls_wise_former.py:457-543) of ONE sub-region
     FusionCouplerFn  selection (:552-560) -> Mutual Cross-region Coupler (FusionClsWiseTransformer.py:43-54) -> scatter + gate
                      (:565-579)
+    IntraCouplerBlockFn / FusionBlockFn   the transformer modules' own forward() on given sequences (same block launches)
 
 Round 1 ran these as ~60 small autograd nodes per region (each Linear, LayerNorm, softmax, mask multiply, add ... its own
 Function): ~800 launches and most of the ATen glue of a step (gradient accumulation of the weight set shared by the four
@@ -291,6 +292,70 @@ class FusionCouplerFn(torch.autograd.Function):
         dX = dx.view(b, t, e)
         dfeats = K.token_grad(dfused, None, R[:, 0:1], inv, None, dX, None, k, cfg.p_select, off, 0)
         return (None, dfeats, dX[:, 0:1]) + (((None,) * NP) if sunk else tuple(Gw[i][0] for i in range(NP)))
+
+
+class IntraCouplerBlockFn(torch.autograd.Function):
+    """TwoClsWiseTransformerModel.forward (ClsWiseTransformer.py:41-55) on four given sequences [B,t,512]:
+        a = CA(edge, sem_supp)  b = CA(sem, edge_supp)  re = CA(a, b)  rs = CA(b, a)  ->  FFN(cat(re, rs))   [B, 2t, 512]
+    -- the same three launch groups (_ca_fwd x 2, _ffn_fwd) RegionCouplerFn runs between its selection and its scatter, for callers
+    that use the module on its own."""
+
+    @staticmethod
+    def forward(ctx, cfg, edge, sem_supp, sem, edge_supp, *flat):
+        K = backend()
+        ctx.set_materialize_grads(False)
+        P = _by_param(flat, 1)
+        b, t, e = edge.shape
+        X1 = torch.stack((edge, sem), 1).contiguous()            # [B,2,t,E]: the pair layout of the coupler kernels
+        X2 = torch.stack((sem_supp, edge_supp), 1).contiguous()
+        rows, z = b * 2 * t, b * 2
+        y1, sv1 = _ca_fwd(K, P, cfg, X1.view(rows, e), X2.view(rows, e), 0, z, t)
+        y2, sv2 = _ca_fwd(K, P, cfg, y1, None, t, z, t)
+        r, sv3 = _ffn_fwd(K, P, cfg, y2)
+        ctx.cfg, ctx.sv, ctx.shape = cfg, (sv1, sv2, sv3), (b, t, e)
+        ctx.save_for_backward(*flat)
+        return r.view(b, 2 * t, e)
+
+    @staticmethod
+    def backward(ctx, dr):
+        K = backend()
+        cfg, (sv1, sv2, sv3) = ctx.cfg, ctx.sv
+        b, t, e = ctx.shape
+        P = _by_param(ctx.saved_tensors, 1)
+        Gw, sunk = _grad_buffers(P)
+        dy2 = _ffn_bwd(K, P, Gw, sv3, dr.contiguous().view(b * 2 * t, e))
+        dy1, _ = _ca_bwd(K, P, Gw, cfg, sv2, dy2, first=True, dual=False)
+        dx1, dx2 = _ca_bwd(K, P, Gw, cfg, sv1, dy1, first=False, dual=True)
+        dX1, dX2 = dx1.view(b, 2, t, e), dx2.view(b, 2, t, e)
+        dP = ((None,) * NP) if sunk else tuple(Gw[i][0] for i in range(NP))
+        return (None, dX1[:, 0], dX2[:, 0], dX1[:, 1], dX2[:, 1]) + dP
+
+
+class FusionBlockFn(torch.autograd.Function):
+    """FusionClsWiseTransformerModel.forward (FusionClsWiseTransformer.py:43-54): FFN(CA(x, x)) on a given sequence [B,t,512]."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, *flat):
+        K = backend()
+        ctx.set_materialize_grads(False)
+        P = _by_param(flat, 1)
+        b, t, e = x.shape
+        y1, sv1 = _ca_fwd(K, P, cfg, x.contiguous().view(b * t, e), None, 0, b, t)
+        r, sv2 = _ffn_fwd(K, P, cfg, y1)
+        ctx.cfg, ctx.sv, ctx.shape = cfg, (sv1, sv2), (b, t, e)
+        ctx.save_for_backward(*flat)
+        return r.view(b, t, e)
+
+    @staticmethod
+    def backward(ctx, dr):
+        K = backend()
+        cfg, (sv1, sv2) = ctx.cfg, ctx.sv
+        b, t, e = ctx.shape
+        P = _by_param(ctx.saved_tensors, 1)
+        Gw, sunk = _grad_buffers(P)
+        dy1 = _ffn_bwd(K, P, Gw, sv2, dr.contiguous().view(b * t, e))
+        dx, _ = _ca_bwd(K, P, Gw, cfg, sv1, dy1, first=True, dual=False)
+        return (None, dx.view(b, t, e)) + (((None,) * NP) if sunk else tuple(Gw[i][0] for i in range(NP)))
 
 
 class _Add3Fn(torch.autograd.Function):

@@ -264,11 +264,9 @@ class _FusedConvFn(torch.autograd.Function):
         K = backend()
         ctx.set_materialize_grads(False)
         spec.uses += 1
-        emul = getattr(K, "name", "") == "emul"
-        w_ref = torch.cat((w0, w1, w2), 0) if emul else None
-        bias = torch.cat((b0, b1, b2), 0) if emul else spec.bias_all
         stats = K.new_stats(x.shape[0], spec.cout, x.device)
-        y = K.conv(spec.op, x, spec.packed(False), bias, spec.cout, None, None, 1.0, None, None, stats, w_ref=w_ref)
+        # (w_ref / bias_ref: the ORIGINAL parameters, which every conv call hands along; the kernels read the packed operands)
+        y = K.conv(spec.op, x, spec.packed(False), spec.bias_all, spec.cout, None, None, 1.0, None, None, stats, w_ref=(w0, w1, w2), bias_ref=(b0, b1, b2))
         sc, sh = K.in_finalize(stats, y.shape[1] * y.shape[2] * y.shape[3])
         ctx.mark_non_differentiable(sc, sh)
         ctx.spec = spec
@@ -301,9 +299,8 @@ class _FusedConvFn(torch.autograd.Function):
             grads = (dwf[:n].view_as(w0), dwf[n:2 * n].view_as(w1), dwf[2 * n:].view_as(w2), db[:c], db[c:2 * c], db[2 * c:])
         dx = None
         if ctx.needs_input_grad[0]:
-            w_ref = torch.cat((w0, w1, w2), 0) if getattr(K, "name", "") == "emul" else None
             dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-            K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dx, w_ref=w_ref, fwd_op=spec.op)
+            K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dx, w_ref=(w0, w1, w2), fwd_op=spec.op)
         return (dx,) + grads + (None,)
 
 
@@ -531,222 +528,10 @@ def tokens_to_window(tok, size, channels, patch):
     return _TokensToWindowFn.apply(tok, tuple(size), channels, tuple(patch))
 
 
-class _SelectFn(torch.autograd.Function):
-    """score = feats . score_tok ; top-k ; gather rows (+pe const, *keep) ; prepend head token.  (:345-350)"""
-
-    @staticmethod
-    def forward(ctx, feats, score_tok, head, k, keep, forced_index):
-        K = backend()
-        if forced_index is None:
-            score = K.token_scores(feats, score_tok)
-            index = K.topk(score, k)
-        else:
-            index = forced_index.to(torch.int32).contiguous()
-        seq = K.gather_tokens(feats, index, head, keep, 1.0)
-        ctx.save_for_backward(index, keep)
-        ctx.fshape, ctx.hshape = feats.shape, head.shape
-        ctx.mark_non_differentiable(index)
-        return seq, index
-
-    @staticmethod
-    def backward(ctx, dseq, _):
-        K = backend()
-        index, keep = ctx.saved_tensors
-        dfeats = torch.zeros(ctx.fshape, dtype=torch.float32, device=dseq.device) if ctx.needs_input_grad[0] else None
-        dhead = torch.zeros(ctx.hshape, dtype=torch.float32, device=dseq.device) if ctx.needs_input_grad[2] else None
-        K.gather_tokens_bwd(dseq, index, keep, dfeats, dhead)
-        return dfeats, None, dhead, None, None, None
-
-
-def select_tokens(feats, score_tok, head, k, keep=None, forced_index=None):
-    return _SelectFn.apply(feats, score_tok.detach(), head, k, keep, forced_index)
-
-
-class _ScatterGateFn(torch.autograd.Function):
-    """scat = feats with rows[index] replaced ; gated = scat * gate.  Returns (gated, scat).  (:463-485)"""
-
-    @staticmethod
-    def forward(ctx, feats, index, rows, gate):
-        K = backend()
-        scat = K.scatter_rows(feats, index, rows, None)
-        gated = K.scatter_rows(feats, index, rows, gate)
-        ctx.save_for_backward(index, scat, gate)
-        ctx.k = index.shape[1]
-        return gated, scat
-
-    @staticmethod
-    def backward(ctx, dgated, dscat):
-        K = backend()
-        index, scat, gate = ctx.saved_tensors
-        dfeats, drows, dgate = K.scatter_rows_bwd(dgated, index, scat, gate, ctx.k)
-        if dscat is not None:
-            df2, dr2, _ = K.scatter_rows_bwd(dscat, index, None, None, ctx.k)
-            dfeats, drows = K.add(dfeats, df2), K.add(drows, dr2)
-        return dfeats, None, drows, dgate
-
-
-def scatter_gate(feats, index, rows, gate):
-    return _ScatterGateFn.apply(feats, index, rows, gate)
-
-
-class _LayerNormFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, gamma, beta):
-        y, mean, rstd = backend().layernorm_fwd(x, gamma, beta)
-        ctx.save_for_backward(x, gamma, mean, rstd)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, gamma, mean, rstd = ctx.saved_tensors
-        dg = torch.empty_like(gamma)         # written, not accumulated (cwf_layernorm_bwd)
-        db = torch.empty_like(gamma)
-        dx = backend().layernorm_bwd(dy, x.contiguous(), gamma, mean, rstd, dg, db)
-        return dx, dg, db
-
-
-def layer_norm(x, gamma, beta):
-    return _LayerNormFn.apply(x, gamma, beta)
-
-
-class _LinearFn(torch.autograd.Function):
-    """y = act(x W^T + b) + residual ; x [B,T,K], W [N,K] (any row-slice view with unit inner stride)."""
-
-    @staticmethod
-    def forward(ctx, x, w, b, act, residual):
-        K = backend()
-        x = x.contiguous()
-        bsz, t, kk = x.shape
-        n = w.shape[0]
-        assert w.stride(1) == 1
-        y = torch.empty((bsz, t, n), dtype=torch.float32, device=x.device)
-        res = residual.contiguous() if residual is not None else None
-        K.gemm(x, (kk, 1, 0, 0), w, (1, w.stride(0), 0, 0), y, (n, 0, 0), bsz * t, n, kk, bias=b, residual=res, sr=(n, 0, 0), act=act)
-        ctx.act, ctx.has_res, ctx.has_b = act, residual is not None, b is not None
-        ctx.save_for_backward(x, w, b)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        K = backend()
-        x, w, b = ctx.saved_tensors
-        dy = dy.contiguous()
-        bsz, t, kk = x.shape
-        n = w.shape[0]
-        m = bsz * t
-        dz = dy
-        if ctx.act:     # recompute the pre-activation (cheap) instead of storing it
-            z = torch.empty_like(dy)
-            K.gemm(x, (kk, 1, 0, 0), w, (1, w.stride(0), 0, 0), z, (n, 0, 0), m, n, kk, bias=b)
-            dz = K.gelu_bwd(z, dy)
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            K.gemm(dz, (n, 1, 0, 0), w, (w.stride(0), 1, 0, 0), dx, (kk, 0, 0), m, kk, n)
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty((n, kk), dtype=torch.float32, device=x.device)
-            K.gemm(dz, (1, n, 0, 0), x, (kk, 1, 0, 0), dw, (kk, 0, 0), n, kk, m)
-        if ctx.has_b and ctx.needs_input_grad[2]:
-            db = K.colsum(dz.view(m, n))
-        return dx, dw, db, None, (dy if ctx.has_res else None)
-
-
-def linear(x, w, b=None, act=0, residual=None):
-    return _LinearFn.apply(x, w, b, act, residual)
-
-
-class _AttnCoreFn(torch.autograd.Function):
-    """softmax(q k^T / sqrt(d)) v over `heads` heads; q [B,Tq,E], kv [B,Tk,2E] (k | v).  (SelfAttention.py:94-98)"""
-
-    @staticmethod
-    def forward(ctx, q, kv, heads, pmask):
-        K = backend()
-        q, kv = q.contiguous(), kv.contiguous()
-        b, tq, e = q.shape
-        tk = kv.shape[1]
-        hd = e // heads
-        p = torch.empty((b, heads, tq, tk), dtype=torch.float32, device=q.device)
-        K.gemm(q, (e, 1, tq * e, hd), kv, (1, 2 * e, tk * 2 * e, hd), p, (tk, heads * tq * tk, tq * tk), tq, tk, hd,
-               zb=b, zh=heads, alpha=hd ** -0.5)
-        K.softmax_rows_(p)
-        pd = K.mul(p, pmask) if pmask is not None else p
-        o = torch.empty((b, tq, e), dtype=torch.float32, device=q.device)
-        K.gemm(pd, (tk, 1, heads * tq * tk, tq * tk), kv, (2 * e, 1, tk * 2 * e, hd), o, (e, tq * e, hd), tq, hd, tk,
-               zb=b, zh=heads, b_off=e)
-        ctx.heads = heads
-        ctx.save_for_backward(q, kv, p, pmask)
-        return o
-
-    @staticmethod
-    def backward(ctx, do):
-        K = backend()
-        q, kv, p, pmask = ctx.saved_tensors
-        do = do.contiguous()
-        heads = ctx.heads
-        b, tq, e = q.shape
-        tk = kv.shape[1]
-        hd = e // heads
-        alpha = hd ** -0.5
-        sp = (tk, 1, heads * tq * tk, tq * tk)          # P as A(m=q,k=key)
-        spt = (1, tk, heads * tq * tk, tq * tk)         # P^T as A(m=key,k=q)
-        pd = K.mul(p, pmask) if pmask is not None else p
-        dkv = torch.empty_like(kv)
-        # dV[key][d] = sum_q Pd[q][key] dO[q][d]
-        K.gemm(pd, spt, do, (e, 1, tq * e, hd), dkv, (2 * e, tk * 2 * e, hd), tk, hd, tq, zb=b, zh=heads, c_off=e)
-        # dPd[q][key] = sum_d dO[q][d] V[key][d]
-        dp = torch.empty_like(p)
-        K.gemm(do, (e, 1, tq * e, hd), kv, (1, 2 * e, tk * 2 * e, hd), dp, (tk, heads * tq * tk, tq * tk), tq, tk, hd,
-               zb=b, zh=heads, b_off=e)
-        if pmask is not None:
-            dp = K.mul(dp, pmask)
-        K.softmax_rows_bwd_(p, dp)                       # dp <- dS
-        dq = torch.empty_like(q)
-        # dQ[q][d] = alpha sum_key dS[q][key] K[key][d]
-        K.gemm(dp, sp, kv, (2 * e, 1, tk * 2 * e, hd), dq, (e, tq * e, hd), tq, hd, tk, zb=b, zh=heads, alpha=alpha)
-        # dK[key][d] = alpha sum_q dS[q][key] Q[q][d]
-        K.gemm(dp, spt, q, (e, 1, tq * e, hd), dkv, (2 * e, tk * 2 * e, hd), tk, hd, tq, zb=b, zh=heads, alpha=alpha)
-        return dq, dkv, None, None
-
-
-def attention_core(q, kv, heads, pmask=None):
-    return _AttnCoreFn.apply(q, kv, heads, pmask)
-
-
-class _MulMaskFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, mask):
-        ctx.save_for_backward(mask)
-        return backend().mul(x, mask)
-
-    @staticmethod
-    def backward(ctx, d):
-        (mask,) = ctx.saved_tensors
-        return backend().mul(d, mask), None
-
-
-class _AddFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, a, b):
-        return backend().add(a, b)
-
-    @staticmethod
-    def backward(ctx, d):
-        return d, d
-
-
-def add(a, b):
-    return _AddFn.apply(a, b)
-
-
 def dropout_mask(shape, p, device, p2=0.0):
     """Pre-scaled keep mask, one launch (K12); p2 > 0 folds a second independent dropout of the same tensor in."""
     return backend().dropout_mask(tuple(shape), float(p), device, float(p2))
 
-
-def dropout(x, p, training):
-    if not training or p <= 0.0:
-        return x
-    return _MulMaskFn.apply(x, dropout_mask(x.shape, p, x.device))
 
 
 # ======================================================================================================

@@ -206,10 +206,11 @@ class HipBackend:
 
     # ------------------------------------------------------------------ K1
     def conv(self, op, x, wpk, bias, cout, in_scale=None, in_shift=None, slope=1.0, residual=None, out_scale=None,
-             stats=None, out=None, w_ref=None, out_channels_alloc=None, fwd_op=None, prec=None, nb=None):
+             stats=None, out=None, w_ref=None, out_channels_alloc=None, fwd_op=None, prec=None, nb=None, bias_ref=None):
         """Returns the output buffer.  With out_channels_alloc > cout the buffer has zero-filled padding channels
         (2-channel heads live in 4-channel tensors so that every later kernel sees 16-byte voxel rows).
-        w_ref / fwd_op are ignored here (the test emulation uses them instead of the packed weights)."""
+        w_ref / bias_ref (the original parameters; tuples for a fused layer) and fwd_op are not read here: the kernels take the
+        packed operands."""
         x, x_ldc = cl(x)
         n, di, hi, wi, cin = x.shape
         if op == pk.CONV3_S2_DGRAD or op == pk.CONVT2_DGRAD:

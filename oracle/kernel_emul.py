@@ -104,10 +104,14 @@ class EmulBackend:
 
     # ------------------------------------------------------------------ K1
     def conv(self, op, x, wpk, bias, cout, in_scale=None, in_shift=None, slope=1.0, residual=None, out_scale=None,
-             stats=None, out=None, w_ref=None, out_channels_alloc=None, fwd_op=None, prec=None):
+             stats=None, out=None, w_ref=None, out_channels_alloc=None, fwd_op=None, prec=None, bias_ref=None):
         """cwf_conv_mfma: F.conv3d / F.conv_transpose3d on act(IN(x)) (+bias, +residual, *out_scale) or, for the
         data-gradient forms (fwd_op given), the adjoint of the forward conv w.r.t. its (activated) input."""
         assert w_ref is not None
+        if isinstance(w_ref, (tuple, list)):               # a fused layer (FusedConvSpec): the sources' parameters, concatenated
+            w_ref = torch.cat(tuple(w_ref), 0)
+        if bias_ref is not None:
+            bias = torch.cat(tuple(bias_ref), 0)
         if fwd_op is None:
             xa = _prologue(x[..., :w_ref.shape[1] if op != CONVT2 else w_ref.shape[0]], in_scale, in_shift, slope)
             y = _fwd_conv(op, xa, w_ref, bias)

@@ -354,3 +354,37 @@ def test_grouped_window_kernels_and_fused_decoupler_conv(hip):
                     close(gb[g], single[g].bias.grad, rtol=5 * tol, what="fused bias grad %d" % g)
         finally:
             kernels.set_precision("fp32")
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_transformer_module_forwards_vs_reference(hip, training):
+    """The coupler modules called on their own, with the reference's signatures (ClsWiseTransformer.py:41-55,
+    FusionClsWiseTransformer.py:43-54): TwoClsWiseTransformerModel(edge, sem_supp, sem, edge_supp) -> [B,258,512] and
+    FusionClsWiseTransformerModel(x) -> [B,129,512] run the fused block launches (cwf.coupler.IntraCouplerBlockFn / FusionBlockFn);
+    outputs and every gradient (inputs + the 13 parameters) against torch autograd through the oracle's restatement.  Training mode
+    with the dropout rates zeroed (masks are device-generated; the dropout sites themselves are covered by
+    test_region_and_fusion_coupler_functions)."""
+    from models.clswiseformer.transformer import TwoClsWiseTransformerModel, FusionClsWiseTransformerModel
+    from oracle import reference_model as rm
+    torch.manual_seed(5)
+    b, t, e = 2, 129, 512
+    for cls, nin in ((TwoClsWiseTransformerModel, 4), (FusionClsWiseTransformerModel, 1)):
+        m = cls(1, 8, e, 0.0, 0.0).to(DEV)
+        m.train(training)
+        xs = [(torch.randn(b, t, e) * 0.5) for _ in range(nin)]
+        xd = [x.to(DEV).requires_grad_(True) for x in xs]
+        out = m(*xd)
+        wgt = torch.linspace(-1, 1, out.numel(), device=DEV).reshape(out.shape)
+        (out * wgt).sum().backward()
+        # oracle: same parameters under the reference's key names, plain torch autograd
+        p = {"T." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+        xr = [x.clone().requires_grad_(True) for x in xs]
+        ref = rm.intra_region_coupler(p, "T", *xr) if nin == 4 else rm.cross_region_coupler(p, "T", xr[0])
+        (ref * wgt.cpu()).sum().backward()
+        assert out.shape == ref.shape
+        assert float((out.detach().cpu() - ref.detach()).abs().max()) <= 2e-4 * float(ref.detach().abs().max())
+        for a_, r_ in zip(xd, xr):
+            assert float((a_.grad.cpu() - r_.grad).norm() / r_.grad.norm()) < 2e-4
+        for k, v in m.named_parameters():
+            g_ref = p["T." + k].grad
+            assert v.grad is not None and float((v.grad.cpu() - g_ref).norm() / (g_ref.norm() + 1e-30)) < 5e-4, k
