@@ -4,6 +4,7 @@
 // FusionClsWiseTransformer.py:43-54.  Sequence length is 129 / 258 tokens x 512: launch-latency bound, so the
 // kernels are kept simple (64x64 or 32x32 workgroup tiles, K steps of 32, one pass).
 #include "common.h"
+#include <cstdlib>
 
 typedef struct cwf_gemm_args GemmArgs;
 
@@ -148,6 +149,170 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmArgs a) {
   }
 }
 
+// The same kernel with 16-byte global loads and K steps of 64.  The scalar form above fetches ONE float per lane and load
+// instruction (8 dword loads per thread and K step of 32): a K step is one L2 round trip long however little it moves, and a
+// 512-deep contraction pays 16 of them (rocprofv3, round 3: 42 us per launch for 0.8 GFLOP).  With float4 loads along each
+// operand's unit-stride dimension a thread issues the same number of load instructions for TWICE the K extent: half the round
+// trips.  Eligibility (alignment of every operand pointer / stride, extents multiples of 4) is checked on the host; anything else
+// takes the scalar kernel.  AK / BN: the unit-stride dimension of A is k (row-major activations, weight^T products) / of B is n.
+template <int TM, int TN, int GK, bool AK, bool BN>
+__global__ __launch_bounds__(256) void gemm_mfma_v_kernel(const GemmArgs a) {
+  constexpr int LDA_S = GK + 1, LDB_S = TN + 16;
+  constexpr int IM = TM / 32, JN = TN / 32;
+  constexpr int SA = TM * GK / 1024, SB = TN * GK / 1024;      // float4 slots per thread
+  __shared__ float As[TM * LDA_S];
+  __shared__ __attribute__((aligned(16))) float Bs[GK * LDB_S];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r = lane & 15, kq = lane >> 4;
+  const int zb = blockIdx.z / a.ZH, zh = blockIdx.z % a.ZH;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+  const int64_t a_zoff = zb * a.sa_zb + zh * a.sa_zh;
+  const float* A = ((a.A2 && n0 >= a.split_n) ? a.A2 : a.A) + a_zoff;
+  const bool tabB = a.B_tab[0] != nullptr;
+  const float* B = tabB ? a.B_tab[blockIdx.z] : a.B + zb * a.sb_zb + zh * a.sb_zh;
+  if (a.B2 && m0 >= a.split_m) B = a.B2 + zb * a.sb_zb + zh * a.sb_zh;
+  const bool a_drop = a.a_drop_p > 0.f;
+  float* rowsum = a.rowsum_tab[0] ? a.rowsum_tab[blockIdx.z] : a.rowsum;
+  const bool do_rs = rowsum != nullptr && blockIdx.x == 0 && wc == 0;
+
+  f32x4 acc[IM][JN], accr[IM];
+#pragma unroll
+  for (int i = 0; i < IM; ++i) {
+    accr[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < JN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  // slot i of this thread: the 4 consecutive elements starting at (am, ak) of A along k (AK) or m; at (bk, bn) of B along n (BN) or k
+  int am[SA], ak[SA], bk[SB], bn[SB];
+#pragma unroll
+  for (int i = 0; i < SA; ++i) {
+    if (AK) { ak[i] = (tid % (GK / 4)) * 4; am[i] = tid / (GK / 4) + (1024 / GK) * i; }
+    else { am[i] = (tid % (TM / 4)) * 4; ak[i] = tid / (TM / 4) + (1024 / TM) * i; }
+  }
+#pragma unroll
+  for (int i = 0; i < SB; ++i) {
+    if (BN) { bn[i] = (tid % (TN / 4)) * 4; bk[i] = tid / (TN / 4) + (1024 / TN) * i; }
+    else { bk[i] = (tid % (GK / 4)) * 4; bn[i] = tid / (GK / 4) + (1024 / GK) * i; }
+  }
+  f32x4 ra[SA], rb[SB];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < SA; ++i) {
+      const int gm = m0 + am[i], gk = k0 + ak[i];
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gm < a.M && gk < a.K) {                          // (extents are multiples of 4 along the vector dimension: all four or none)
+        const int64_t off = gm * a.sa_m + gk * a.sa_k;
+        v = *reinterpret_cast<const f32x4*>(A + off);
+        if (a_drop) {
+          const int64_t st = AK ? 1 : a.sa_m;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] *= cwf_keep(a.rng, a.a_drop_off, (uint64_t)(a_zoff + off + c * st), a.a_drop_n, a.a_drop_p, a.a_drop_p2);
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+      const int gn = n0 + bn[i], gkb = k0 + bk[i];
+      rb[i] = (gn < a.N && gkb < a.K) ? *reinterpret_cast<const f32x4*>(B + gkb * a.sb_k + gn * a.sb_n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < a.K; k0 += GK) {
+    if (k0) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SA; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (AK) As[am[i] * LDA_S + ak[i] + c] = ra[i][c];
+        else As[(am[i] + c) * LDA_S + ak[i]] = ra[i][c];
+      }
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+      if (BN) *reinterpret_cast<f32x4*>(&Bs[bk[i] * LDB_S + bn[i]]) = rb[i];
+      else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Bs[(bk[i] + c) * LDB_S + bn[i]] = rb[i][c];
+      }
+    }
+    __syncthreads();
+    if (k0 + GK < a.K) fetch(k0 + GK);          // in flight while the MFMAs below run
+#pragma unroll
+    for (int kk = 0; kk < GK / 4; ++kk) {
+      float av[IM], bv[JN];
+#pragma unroll
+      for (int i = 0; i < IM; ++i) av[i] = As[(wr * (TM / 2) + i * 16 + r) * LDA_S + kk * 4 + kq];
+#pragma unroll
+      for (int j = 0; j < JN; ++j) bv[j] = Bs[(kk * 4 + kq) * LDB_S + wc * (TN / 2) + j * 16 + r];
+#pragma unroll
+      for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int j = 0; j < JN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+      if (do_rs) {
+#pragma unroll
+        for (int i = 0; i < IM; ++i) accr[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], 1.0f, accr[i], 0, 0, 0);
+      }
+    }
+  }
+  // ---- epilogue: identical to the scalar kernel
+  const int64_t c_zoff = zb * a.sc_zb + zh * a.sc_zh;
+  float* C = a.C_tab[0] ? a.C_tab[blockIdx.z] : a.C + c_zoff;
+  float* C2 = a.C2 ? a.C2 + c_zoff : nullptr;
+  const float* bias = a.bias_tab[0] ? a.bias_tab[blockIdx.z] : a.bias;
+  const float* R = a.residual ? a.residual + zb * a.sr_zb + zh * a.sr_zh : nullptr;
+  const bool c_drop = a.c_drop_p > 0.f;
+#pragma unroll
+  for (int i = 0; i < IM; ++i)
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+      const int gn = n0 + wc * (TN / 2) + j * 16 + r;
+      if (gn >= a.N) continue;
+      const float bv = bias ? bias[gn] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int gm = m0 + wr * (TM / 2) + i * 16 + kq * 4 + e;
+        if (gm >= a.M) continue;
+        const int64_t off = gm * a.sc_m + gn;
+        float v = acc[i][j][e] * a.alpha + bv;
+        if (C2) C2[off] = v;
+        if (a.act == 1) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        if (c_drop) v *= cwf_keep(a.rng, a.c_drop_off, (uint64_t)(c_zoff + off), a.c_drop_n, a.c_drop_p, a.c_drop_p2);
+        if (R) v += R[gm * a.sr_m + gn];
+        float* p = C + off;
+        if (a.accumulate) v += *p;
+        *p = v;
+      }
+    }
+  if (do_rs && r == 0) {
+#pragma unroll
+    for (int i = 0; i < IM; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int gm = m0 + wr * (TM / 2) + i * 16 + kq * 4 + e;
+        if (gm < a.M) rowsum[gm] = (a.rowsum_acc ? rowsum[gm] : 0.f) + accr[i][e];
+      }
+  }
+}
+
+// every pointer / stride the vector kernel dereferences with 16-byte loads
+static bool gemm_vec_ok(const GemmArgs& a, bool* ak, bool* bn) {
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  auto m4 = [](int64_t v) { return (v & 3) == 0; };
+  if (!m4(a.sa_zb) || !m4(a.sa_zh) || !m4(a.sb_zb) || !m4(a.sb_zh)) return false;
+  if (!al(a.A) || (a.A2 && !al(a.A2)) || (a.B && !al(a.B)) || (a.B2 && !al(a.B2))) return false;
+  for (int z = 0; z < 4; ++z)
+    if (a.B_tab[z] && !al(a.B_tab[z])) return false;
+  if (a.sa_k == 1 && m4(a.K) && m4(a.sa_m)) *ak = true;
+  else if (a.sa_m == 1 && m4(a.M) && m4(a.sa_k)) *ak = false;
+  else return false;
+  if (a.sb_n == 1 && m4(a.N) && m4(a.sb_k)) *bn = true;
+  else if (a.sb_k == 1 && m4(a.K) && m4(a.sb_n)) *bn = false;
+  else return false;
+  if (a.B2 && (a.split_m & 3)) return false;
+  return true;
+}
+
 extern "C" int cwf_gemm_ex(const struct cwf_gemm_args* args, void* stream) {
   if (!args) return CWF_E_BADARG;
   const GemmArgs& a = *args;
@@ -160,6 +325,18 @@ extern "C" int cwf_gemm_ex(const struct cwf_gemm_args* args, void* stream) {
   for (int z = 0; z < a.ZB && z < 4; ++z)
     if ((a.B_tab[0] && !a.B_tab[z]) || (a.bias_tab[0] && !a.bias_tab[z]) || (a.C_tab[0] && !a.C_tab[z]) || (a.rowsum_tab[0] && !a.rowsum_tab[z])) return CWF_E_BADARG;
   const int64_t wg64 = (int64_t)cdiv(a.N, 64) * cdiv(a.M, 64) * a.ZB * a.ZH;
+  static const bool no_vec = getenv("CWF_GEMM_SCALAR") != nullptr;      // A/B switch: the scalar-load kernel for everything
+  bool ak = false, bn = false;
+  if (!no_vec && a.K >= 64 && gemm_vec_ok(a, &ak, &bn)) {
+    const bool big = wg64 >= 256;
+    dim3 grid(cdiv(a.N, big ? 64 : 32), cdiv(a.M, big ? 64 : 32), a.ZB * a.ZH);
+#define CWF_GV(AKv, BNv) do { if (big) hipLaunchKernelGGL((gemm_mfma_v_kernel<64, 64, 32, AKv, BNv>), grid, dim3(256), 0, cwf_stream(stream), a); \
+                              else hipLaunchKernelGGL((gemm_mfma_v_kernel<32, 32, 64, AKv, BNv>), grid, dim3(256), 0, cwf_stream(stream), a); } while (0)
+    if (ak && bn) CWF_GV(true, true); else if (ak) CWF_GV(true, false); else if (bn) CWF_GV(false, true); else CWF_GV(false, false);
+#undef CWF_GV
+    CWF_LAUNCH_CHECK();
+    return 0;
+  }
   if (wg64 >= 256) {
     dim3 grid(cdiv(a.N, 64), cdiv(a.M, 64), a.ZB * a.ZH);
     hipLaunchKernelGGL((gemm_mfma_kernel<64, 64, 32>), grid, dim3(256), 0, cwf_stream(stream), a);

@@ -183,7 +183,9 @@ class Trainer:
         self._static = (x.clone(), target.clone(), edge.clone())
         want_plan = self.graph_mode == "plan"
         g = torch.cuda.CUDAGraph(keep_graph=True) if want_plan else torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread-local capture mode: with a process group alive, RCCL's watchdog thread polls events while this thread captures; in the
+        # default (global) mode any such call from another thread invalidates the capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._static_out = self._fwd_bwd(*self._static)
         self._graph = g
         if want_plan:
