@@ -18,9 +18,11 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 // Workgroups of the persistent weight-gradient kernels (wgrad16, wgrad_s1, pw_wgrad: 10-16 waves each, most of a CU's registers).
 // They run on the side stream BESIDE the main stream's kernels: at one workgroup per CU (256) a main-stream workgroup often finds
-// no CU with room and waits for a whole side kernel; 192 leaves a quarter of the CUs to the main stream (in the step: 99.3 -> 100.1
-// volumes/s, although an isolated launch is slower).  CWF_SIDE_WGS overrides (multiple of 8).
-static int side_wgs() { static const int v = getenv("CWF_SIDE_WGS") ? atoi(getenv("CWF_SIDE_WGS")) : 192; return v; }
+// no CU with room and waits for a whole side kernel; fewer workgroups leave CUs to the main stream (an isolated launch is slower,
+// the step faster).  Round 2, launches from Python: 192 (99.3 -> 100.1 volumes/s).  Round 3, launch plan (the main stream never
+// waits for the host any more): 128 -- 64 / 96 / 128 / 160 / 192 / 256 give 91.3 / 99.9 / 104.8 / 103.7 / 103.1 / 102.6 volumes/s.
+// CWF_SIDE_WGS overrides (multiple of 8).
+static int side_wgs() { static const int v = getenv("CWF_SIDE_WGS") ? atoi(getenv("CWF_SIDE_WGS")) : 128; return v; }
 
 struct WgArgsB {
   ConvGeom g;

@@ -90,7 +90,10 @@ class Trainer:
         # beside the backward of the supervision heads / couplers -- 10-20 us kernels behind ~35 us of Python each, where the main
         # stream idles 1.7 ms per step -- instead of competing with the decoder's own HBM-bound data gradients (95.6 -> 96.7
         # volumes/s; neutral while the step was still bound elsewhere).  CWF_DEFER_WGRAD=0 launches them immediately.
-        self.defer_level = int(os.environ.get("CWF_DEFER_WGRAD", "1"))
+        # Level 2 also holds the heads / couplers / decouplers phase's ~40 small weight-gradient launches until backward is in the
+        # encoder.  Round 3 (launch plan: the host is never the bound): level 2 is the default there (103.1 -> 104.8 volumes/s with 128
+        # side workgroups); launches from Python keep level 1.
+        self.defer_level = int(os.environ.get("CWF_DEFER_WGRAD", "2" if self.graph_mode == "plan" else "1"))
         self.defer_decoder_wgrad = self.defer_level >= 1
 
     # ------------------------------------------------------------------------------------------------
@@ -234,6 +237,9 @@ class Trainer:
         if self.use_graph and self._graph is None and self._eager_steps >= self._graph_warmup:
             torch.cuda.synchronize()
             self._capture(x, target, edge)
+        if self._graph is not None and tuple(x.shape) != tuple(self._static[0].shape):
+            raise ValueError("this Trainer captured its step for inputs of shape %s; got %s (a captured step is shape-static: use "
+                             "use_graph=False for varying shapes)" % (tuple(self._static[0].shape), tuple(x.shape)))
         if self._graph is not None:
             sx, st, se = self._static
             if sx.data_ptr() != x.data_ptr():

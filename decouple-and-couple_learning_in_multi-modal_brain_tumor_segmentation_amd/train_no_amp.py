@@ -78,6 +78,10 @@ def build_parser():
     # additions of this implementation
     p.add_argument("--synthetic", default=0, type=int, help="train on N generator-defined subjects instead of files under --root")
     p.add_argument("--precision", default="bf16x3", choices=("fp32", "bf16x3", "bf16"))
+    p.add_argument("--step_mode", default="eager", choices=("eager", "plan", "hipgraph"),
+                   help="plan: the step (fixed crop size and batch) is captured once and re-issued by the library as a launch list "
+                        "(cwf.trainer: ~2 ms of host time per step instead of ~8-14); the last, smaller batch of an epoch would not fit "
+                        "the capture, so it is dropped in this mode")
     p.add_argument("--log_every", default=10, type=int)
     p.add_argument("--max_iters", default=0, type=int, help="stop after this many iterations (smoke runs); 0 = no limit")
     p.add_argument("--backend", default=None, type=str, help="torch.distributed backend (default: nccl = RCCL on GPU, gloo on CPU)")
@@ -146,7 +150,8 @@ def main(argv=None):
             log.info("loaded checkpoint %s, training from epoch %d", args.resume, args.start_epoch)
     elif is_printer:
         log.info("re-training!!!")
-    trainer = Trainer(model, lr=args.lr, weight_decay=args.weight_decay, amsgrad=args.amsgrad, end_epoch=args.end_epoch)
+    trainer = Trainer(model, lr=args.lr, weight_decay=args.weight_decay, amsgrad=args.amsgrad, end_epoch=args.end_epoch,
+                      use_graph={"eager": False, "plan": "plan", "hipgraph": "hipgraph"}[args.step_mode] if use_cuda else False)
 
     ckpt_dir = os.path.join(args.project_root, "checkpoint", args.experiment + args.date)
     if is_printer:
@@ -159,7 +164,7 @@ def main(argv=None):
             ds.set_epoch(epoch)
         mine = shard_indices(len(ds), rank, world, epoch=epoch, shuffle=True, seed=args.seed)      # DistributedSampler semantics
         loader = torch.utils.data.DataLoader(torch.utils.data.Subset(ds, mine), batch_size=args.batch_size, shuffle=False,
-                                             drop_last=False, num_workers=args.num_workers if use_cuda else 0, pin_memory=use_cuda)
+                                             drop_last=(args.step_mode != "eager" and use_cuda), num_workers=args.num_workers if use_cuda else 0, pin_memory=use_cuda)
         for i, (x, target, edge, _missing) in enumerate(loader):
             x, target, edge = (t.to(device, non_blocking=True) for t in (x, target, edge))
             loss, parts = trainer.step(x, target, edge, epoch)

@@ -243,6 +243,10 @@ def test_training_harness_on_gpu(hip, tmp_path):
     rc = tn.main(["--synthetic", "2", "--crop_H", "64", "--crop_W", "64", "--crop_D", "64", "--end_epoch", "2", "--max_iters", "3",
                   "--log_every", "1", "--num_workers", "0", "--batch_size", "2", "--project_root", str(tmp_path), "--experiment", "g", "--date", "d"])
     assert rc == 0
+    # the same harness with the step captured once and re-issued as a launch list (two eager steps, the capture, three listed steps)
+    rc = tn.main(["--synthetic", "2", "--crop_H", "64", "--crop_W", "64", "--crop_D", "64", "--end_epoch", "6", "--max_iters", "6", "--step_mode", "plan",
+                  "--log_every", "1", "--num_workers", "0", "--batch_size", "2", "--project_root", str(tmp_path), "--experiment", "p", "--date", "d"])
+    assert rc == 0
     ck = torch.load(tmp_path / "checkpoint" / "gd" / "model_epoch_last.pth", weights_only=True)
     assert len(ck["state_dict"]) == 222 and all(k.startswith("module.") for k in ck["state_dict"])
     from cwf import kernels
