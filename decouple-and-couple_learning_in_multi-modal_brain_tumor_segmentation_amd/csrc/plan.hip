@@ -171,10 +171,14 @@ extern "C" int cwf_plan_create(void* graph_, void** out) {
             return CWF_E_TOOLARGE;       // not a step this library captured
         }
     }
-    // ---- chains.  depth[v] = longest path from v to a sink.  A node hands its stream to the successor with the largest depth (the
-    // main stream's data-gradient chain is by far the longest); every other successor continues another predecessor's stream, takes a
-    // side stream whose chain has ended, or opens one.  Any assignment is CORRECT (same-stream edges are FIFO order, cross-stream
-    // edges get an event); the choice only decides what may overlap.
+    // ---- chains.  depth[v] = longest path from v to a sink.  A node hands its stream to ONE successor: a successor that has no other
+    // predecessor if there is one (under stream capture the next node of the SAME stream depends on its predecessor alone, whereas a
+    // node of another stream that waited for an event here also depends on that stream's tail), else -- and among several such -- the
+    // one with the largest depth (the main stream's data-gradient chain is by far the longest).  Depth alone is not enough: late in
+    // backward the serialised weight-gradient chain is DEEPER than what is left of the main stream, and handing stream 0 to it split
+    // the main chain over extra streams (4 streams, 33 ms per step instead of 19).  Every other successor continues another
+    // predecessor's stream, takes a side stream whose chain has ended, or opens one.  Any assignment is CORRECT (same-stream edges
+    // are FIFO order, cross-stream edges get an event); the choice only decides what may overlap.
     std::vector<int> depth(n, 1);
     for (int i = (int)n - 1; i >= 0; --i) {
         int u = order[i];
@@ -185,7 +189,10 @@ extern "C" int cwf_plan_create(void* graph_, void** out) {
         int best = -1;
         for (int v : succ[u]) {
             if (P->nodes[pos[v]].kind == NK_MARKER) continue;
-            if (best < 0 || depth[v] > depth[best] || (depth[v] == depth[best] && pos[v] < pos[best])) best = v;
+            if (best < 0) { best = v; continue; }
+            const bool sv = pred[v].size() == 1, sb = pred[best].size() == 1;
+            if (sv != sb) { if (sv) best = v; continue; }
+            if (depth[v] > depth[best] || (depth[v] == depth[best] && pos[v] < pos[best])) best = v;
         }
         heir[u] = best;
     }

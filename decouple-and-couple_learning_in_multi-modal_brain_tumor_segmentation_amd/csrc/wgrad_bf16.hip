@@ -22,6 +22,7 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 // the step faster).  Round 2, launches from Python: 192 (99.3 -> 100.1 volumes/s).  Round 3, launch plan (the main stream never
 // waits for the host any more): 128 -- 64 / 96 / 128 / 160 / 192 / 256 give 91.3 / 99.9 / 104.8 / 103.7 / 103.1 / 102.6 volumes/s.
 // CWF_SIDE_WGS overrides (multiple of 8).
+extern "C" int cwf_wgrad_nsplit(int op, int N, int Do, int Ho, int Wo, int Cin, int Cout);
 static int side_wgs() { static const int v = getenv("CWF_SIDE_WGS") ? atoi(getenv("CWF_SIDE_WGS")) : 128; return v; }
 
 struct WgArgsB {
@@ -720,6 +721,182 @@ __global__ __launch_bounds__(256 + 64 * W16_LW) void wgrad16_kernel(const WgArgs
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad16d: wgrad16 on bf16 OPERAND IMAGES filled by LDS-DMA.  Both operands arrive as bf16 tensors [N][D][H][W][16] -- xa16 =
+// bf16(act(IN(x))) written as a side output by the layer's own InstanceNorm-backward apply pass (which has x and its statistics in
+// registers anyway), dy16 = the bf16 image of the incoming gradient written by the pass that produced it (norm.hip) -- i.e. exactly
+// the values wgrad16's loaders compute per tile from the fp32 tensors (single-bf16 operand products; bit-identical operands).
+// What that buys (profiles/round3_conv16s_wgrad_pmc.txt: wgrad16 moves 1.9x its algorithmic bytes from L2 and is bound by one
+// tile of register-staged loads in flight per CU, 26 GB/s per CU at the step's 128 workgroups):
+//   * half the bytes (32 B per voxel and operand instead of 64);
+//   * no conversion, no registers: the six loader waves only issue global_load_lds_dwordx4 pieces (1 KiB of LDS each, 33 per tile),
+//     so THREE tiles are in flight per CU in a four-buffer LDS ring behind counted vmcnt waits and one raw s_barrier per tile;
+//   * zero padding = out-of-range lanes read a 16-byte zero page.
+// LDS image = wgrad16's (voxel-major rows padded to 20 voxels = 640 B = 40 granules of 16 B: conflict-free transposed reads); a
+// piece is 64 consecutive granules, per-lane source address; pad granules read the zero page.  MFMA waves: wgrad16's.
+// ---------------------------------------------------------------------------------------------------
+#define W16D_XP 23                                      // DMA pieces of the x image (36 rows x 40 granules = 1440 -> 23 pieces)
+#define W16D_DP 10                                      // DMA pieces of the dy image (16 rows x 40 granules = 640)
+#define W16D_XIB (W16D_XP * 1024)
+#define W16D_BUFB ((W16D_XP + W16D_DP) * 1024)          // 33,792 B per buffer
+#define W16D_NBUF 4
+#define W16D_LW 6                                       // loader waves
+struct W16dArgs {
+  const uint4* xa; const uint4* dy; const uint4* zero; float* partial;
+  int N, D, H, W, tiles_d, tiles_h, tiles_w, total_tiles;
+  int64_t slab_floats;
+};
+
+__global__ __launch_bounds__(256 + 64 * W16D_LW) void wgrad16d_kernel(const W16dArgs a) {
+  extern __shared__ float4 lds4[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_sp = a.tiles_d * a.tiles_h * a.tiles_w;
+  const int G = (int)gridDim.x, per = G >> 3;
+  const int first = (blockIdx.x & 7) * per + (blockIdx.x >> 3);      // tile(it) = first + it * G   (XCD-aware, see wgrad16_kernel)
+  const int niter = first < a.total_tiles ? (a.total_tiles - first + G - 1) / G : 0;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds4;
+
+  if (wave < 4) {
+    // =============================================================== MFMA waves (wgrad16_kernel<false>, four buffers)
+    const int kq = lane >> 4;
+    const int bq = (lane & 15) >> 2, bp = lane & 3;
+    f32x4 acc[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
+    const unsigned lane_x = lds_base + (((kq & 1) * W16_XW + (kq >> 1) * 8 + bq) * 16 + bp * 4) * 2;
+    unsigned xa[7];
+    unsigned da = lds_base + W16D_XIB + (((kq & 1) * W16_DW + (kq >> 1) * 8 + bq) * 16 + bp * 4) * 2;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int t = wave + 4 * i;
+      xa[i] = lane_x + (t < 27 ? (((t / 9) * 6 + (t / 3) % 3) * W16_XW + t % 3) * 32 : 0);
+    }
+    auto trf = [&](unsigned addr) {
+      const s16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)addr);
+      const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(addr + 4 * 32));
+      const s16x8 w = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+      return __builtin_bit_cast(bf16x8, w);
+    };
+    auto tiles = [&](auto BIAS_) {
+      constexpr bool BIAS = decltype(BIAS_)::value;
+      constexpr int DEPTH = CWF_W16_DEPTH;
+      for (int it = 0; it < niter; ++it) {
+        asm volatile("s_barrier" ::: "memory");          // buffer it & 3 has landed
+        bf16x8 ah[DEPTH + 1], bh[2];
+        auto issue = [&](int f) {
+          const int ks = f / 7, i = f % 7;
+          if (i == 0) bh[ks & 1] = trf(da + (2 * ks * W16_DW) * 32);
+          if (!(BIAS && i == 6)) ah[f % (DEPTH + 1)] = trf(xa[i] + (((ks >> 1) * 6 + ((2 * ks) & 3)) * W16_XW) * 32);
+        };
+#pragma unroll
+        for (int f = 0; f < DEPTH; ++f) issue(f);
+#pragma unroll
+        for (int f = 0; f < 56; ++f) {
+          if (f + DEPTH < 56) issue(f + DEPTH);
+          __builtin_amdgcn_sched_barrier(0);
+          const int ks = f / 7, i = f % 7;
+          const bf16x8 bhf = bh[ks & 1];
+          if (BIAS && i == 6) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bhf, acc[i], 0, 0, 0);
+          else acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f % (DEPTH + 1)], bhf, acc[i], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+          const unsigned dlt = ((it & 3) == 3) ? (unsigned)(-(3 * W16D_BUFB)) : (unsigned)W16D_BUFB;
+#pragma unroll
+          for (int i = 0; i < 7; ++i) xa[i] += dlt;
+          da += dlt;
+        }
+      }
+    };
+    if (wave == 3) tiles(std::true_type{}); else tiles(std::false_type{});
+    float4* out = reinterpret_cast<float4*>(a.partial + (int64_t)blockIdx.x * a.slab_floats);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int t = wave + 4 * i;
+      if (t > 27) continue;
+      out[(int64_t)t * 64 + lane] = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+    }
+  } else {
+    // =============================================================== loader waves: DMA only
+    const int lw = wave - 4;                               // pieces lw, lw + 6, ... of the 33
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef __attribute__((address_space(1))) const void* glb_vp;
+    auto run = [&](auto NI_) __attribute__((always_inline)) {
+      constexpr int NI = decltype(NI_)::value;
+      int off[NI]; unsigned crd[NI];                       // granule offset from the tile's operand origin; (c0, c1, w, valid)
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int s = lw + W16D_LW * k;
+        const bool isd = s >= W16D_XP;
+        const int gi = 64 * (isd ? s - W16D_XP : s) + lane;
+        const int row = gi / 40, gr = gi % 40, w = gr >> 1, half = gr & 1;
+        const int c0 = isd ? (row >> 2) : row / 6, c1 = isd ? (row & 3) : row % 6;
+        const bool valid = isd ? gr < 32 : (row < 36 && gr < 36);
+        off[k] = ((c0 * a.H + c1) * a.W + w) * 2 + half;
+        crd[k] = (unsigned)c0 | ((unsigned)c1 << 3) | ((unsigned)w << 6) | (valid ? 1u << 11 : 0u);
+      }
+      auto issue = [&](int it) __attribute__((always_inline)) {
+        const int tile = first + it * G;
+        const int n = tile / tiles_sp; int rem = tile - n * tiles_sp;
+        const int tile_w = rem % a.tiles_w; rem /= a.tiles_w;
+        const int tile_h = rem % a.tiles_h; const int tile_d = rem / a.tiles_h;
+        const int od0 = tile_d * 4, oh0 = tile_h * 4, ow0 = tile_w * 16;
+        const int64_t vd = (((int64_t)n * a.D + od0) * a.H + oh0) * a.W + ow0;       // voxel index of the dy tile origin
+        const int64_t vx = vd - ((int64_t)a.H + 1) * a.W - 1;                        // ... of the x halo origin (-1, -1, -1)
+        const unsigned lbuf = lds_base + (unsigned)(it & 3) * W16D_BUFB;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+          const int s = lw + W16D_LW * k;                 // (wave-uniform)
+          const bool isd = s >= W16D_XP;
+          const int c0 = (int)(crd[k] & 7u), c1 = (int)((crd[k] >> 3) & 7u), w = (int)((crd[k] >> 6) & 31u);
+          const int gd = (isd ? od0 : od0 - 1) + c0, gh = (isd ? oh0 : oh0 - 1) + c1, gw = (isd ? ow0 : ow0 - 1) + w;
+          const bool ok = (crd[k] >> 11) != 0u && (unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
+          const uint4* src = (isd ? a.dy + vd * 2 : a.xa + vx * 2) + off[k];
+          src = ok ? src : a.zero;
+          __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(uintptr_t)(lbuf + (unsigned)s * 1024u), 16, 0, 0);
+        }
+      };
+      if (niter > 0) issue(0);
+      if (niter > 1) issue(1);
+      if (niter > 2) issue(2);
+      for (int it = 0; it < niter; ++it) {
+        // tile `it` has landed once all but the pieces of the (at most two) younger tiles in flight are done
+        if (it + 2 < niter) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (it + 3 < niter) issue(it + 3);               // into the buffer the MFMA waves finished before this barrier
+      }
+    };
+    if (lw < (W16D_XP + W16D_DP) % W16D_LW) run(std::integral_constant<int, (W16D_XP + W16D_DP) / W16D_LW + 1>{});
+    else run(std::integral_constant<int, (W16D_XP + W16D_DP) / W16D_LW>{});
+  }
+}
+
+extern "C" int cwf_wgrad16_bf16(const void* xa16, const void* dy16, const void* zero16, float* partial,
+                                int N, int D, int H, int W, int* nsplit_used, void* stream) {
+  if (!xa16 || !dy16 || !zero16 || !partial || N <= 0 || D <= 0 || H <= 0 || W <= 0) return CWF_E_BADARG;
+  if (((uintptr_t)xa16 & 15) || ((uintptr_t)dy16 & 15) || ((uintptr_t)zero16 & 15) || ((uintptr_t)partial & 15)) return CWF_E_ALIGN;
+  if ((int64_t)N * D * H * W >= (1ll << 30)) return CWF_E_TOOLARGE;
+  W16dArgs a;
+  a.xa = (const uint4*)xa16; a.dy = (const uint4*)dy16; a.zero = (const uint4*)zero16; a.partial = partial;
+  a.N = N; a.D = D; a.H = H; a.W = W;
+  a.tiles_d = cdiv(D, 4); a.tiles_h = cdiv(H, 4); a.tiles_w = cdiv(W, 16);
+  a.total_tiles = N * a.tiles_d * a.tiles_h * a.tiles_w;
+  a.slab_floats = 28 * 256;                               // = cwf_wgrad_slab_floats(CWF_CONV3_S1, 16, 16)
+  int grid = side_wgs(); while (grid > 8 && grid > a.total_tiles) grid -= 8;      // multiple of 8 (XCD-aware tile map)
+  if (grid > cwf_wgrad_nsplit(CWF_CONV3_S1, N, D, H, W, 16, 16)) return CWF_E_BADARG;    // (the caller's slab buffer is sized by it)
+  const size_t lds = (size_t)W16D_NBUF * W16D_BUFB;
+  CWF_MAX_LDS_ONCE((&wgrad16d_kernel));
+  hipLaunchKernelGGL(wgrad16d_kernel, dim3(grid), dim3(256 + 64 * W16D_LW), lds, cwf_stream(stream), a);
+  CWF_LAUNCH_CHECK();
+  if (nsplit_used) *nsplit_used = grid;
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -162,10 +162,12 @@ class WeightPacker:
 # ======================================================================================================
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, spec, in_scale, in_shift, slope, residual, out_scale, want_stats, carry, x_link, out=None):
+    def forward(ctx, x, w, b, spec, in_scale, in_shift, slope, residual, out_scale, want_stats, carry, x_link, out=None, res_link=None,
+                carry_link=None):
         K = backend()
         ctx.set_materialize_grads(False)     # (autograd would zero-FILL a gradient for each of the (scale, shift) outputs: 2 launches per conv)
         ctx.x_link = x_link
+        ctx.res_link, ctx.carry_link = res_link, carry_link
         if spec.dev is not None and x.device != spec.dev:
             # packed weights, index maps and kernel attributes of a layer live on ONE device; a multi-device nn.DataParallel replica
             # would launch with another device's pointers (a GPU memory fault): one process per GPU is the supported layout
@@ -181,6 +183,11 @@ class _ConvFn(torch.autograd.Function):
         ctx.spec, ctx.slope = spec, slope
         ctx.bias_ref = b
         ctx.has_res = residual is not None
+        # bf16 operand images for this layer's weight gradient (full-resolution 16-channel layers, HipBackend.bf16_operands_ok)
+        ok16 = getattr(K, "bf16_operands_ok", None)
+        ctx.use16 = bool(ok16 is not None and ok16(spec.op, spec.cin, spec.cout, y.shape[1] * y.shape[2] * y.shape[3]))
+        ctx.x16 = getattr(x, "_cwf16x", None) if (ctx.use16 and in_scale is None) else None     # bf16(x) from x's producer (a block tail)
+        ctx.up16 = bool(getattr(x, "_cwf_want16", False))     # x's producer is such a layer: hand its gradient on with a bf16 image
         ctx.save_for_backward(x, w, in_scale, in_shift, out_scale)
         # carry: x is handed on as a second output (an alias).  Whatever consumes that alias (a residual connection, a skip
         # connection) sends its gradient back HERE, where it is folded into the kernel that writes dx (dx_add of the
@@ -196,39 +203,33 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _a, _b, dcarry):
         K = backend()
+        if ctx.carry_link is not None and ctx.carry_link.grads:
+            # gradients the consumers of the carried alias handed over directly (CarryLink) join whatever autograd delivered
+            for gq in ctx.carry_link.grads:
+                dcarry = gq if dcarry is None else K.add(dcarry, gq)
+            ctx.carry_link.grads = []
         if dy is None:                       # y itself unused downstream: only the carried alias has a gradient
-            return dcarry, None, None, None, None, None, None, None, None, None, None, None, None
+            return (dcarry,) + (None,) * 14
         x, w, in_scale, in_shift, out_scale = ctx.saved_tensors
         spec = ctx.spec
         if out_scale is not None:
             dy = K.channel_scale(dy, out_scale)
         dres = dy if ctx.has_res else None
+        dy_private = not ctx.has_res
+        if ctx.has_res and ctx.res_link is not None:
+            # the residual is a carried alias: its gradient (= dy) goes to the producing conv's backward through the link, not through
+            # autograd -- dy stays a tensor only this code references, so the side stream may read it (see CarryLink)
+            ctx.res_link.grads.append(dy)
+            dres = None
+            dy_private = True
         dw = db = dx = None
         sink = active_sink()
         sw = sink.view(w) if (sink is not None and spec.uses <= 1 and ctx.needs_input_grad[1]) else None
         sb = sink.view(ctx.bias_ref) if (sw is not None and ctx.bias_ref is not None) else None
-        if sw is not None and (ctx.bias_ref is None or sb is not None):
-            # gradient-sink path (Trainer): slabs now, ONE batched reduce per backward phase writes dW / db into the flat buffer
-            dyv = dy[..., :spec.cout] if dy.shape[-1] != spec.cout else dy
-            K.wgrad_to(spec, spec.op, x, in_scale, in_shift, ctx.slope, dyv, spec.cout, spec.inv_map, sw, sb if spec.has_bias_map else None,
-                       allow_async=not ctx.has_res)
-            sink.mark(w)
-            if sb is not None:
-                if not spec.has_bias_map:   # ConvTranspose: the bias gradient spans the 8 parity classes
-                    K.stats_channel_sum(K.in_stats(dy), sb)
-                sink.mark(ctx.bias_ref)
-        elif ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            dyv = dy[..., :spec.cout] if dy.shape[-1] != spec.cout else dy
-            # side-stream weight gradients only where nothing on the main stream can touch their operands or results early:
-            #  * a weight applied twice in the forward, or a .grad that already exists, makes AccumulateGrad add IN PLACE;
-            #  * with a residual, dy itself is handed on as the residual's gradient and the engine may accumulate into it
-            #    in place while the side stream still reads it (record_stream guards reuse, not modification)
-            once = spec.uses <= 1 and w.grad is None and not ctx.has_res
-            dwf, db = K.wgrad(spec.op, x, in_scale, in_shift, ctx.slope, dyv, spec.cout, spec.inv_map, spec.has_bias_map, w.numel(), w_ref_shape=w.shape,
-                              allow_async=once)
-            dw = dwf.view(w.shape)
-            if db is None:      # ConvTranspose: bias gradient spans the 8 parity classes
-                db = K.stats_channel_sum(K.in_stats(dy), torch.empty(spec.cout, dtype=torch.float32, device=dy.device))
+        to_sink = sw is not None and (ctx.bias_ref is None or sb is not None)
+        use16 = ctx.use16 and to_sink and out_scale is None
+        dy16 = getattr(dy, "_cwf16", None) if use16 else None
+        xa16 = ctx.x16 if use16 else None
         if ctx.needs_input_grad[0]:
             dxa = torch.empty(x.shape, dtype=torch.float32, device=x.device)
             fused = in_scale is not None and getattr(K, "supports_fused_norm_bwd", lambda: False)()
@@ -237,7 +238,17 @@ class _ConvFn(torch.autograd.Function):
                 sums = K.new_stats(x.shape[0], spec.cin, x.device)
                 K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op,
                        stats=sums, nb=(x, in_scale, in_shift, ctx.slope))
-                dx = K.in_bwd_apply(dxa, x, in_scale, in_shift, ctx.slope, sums, dx_add=dcarry)
+                emits = getattr(K, "APPLY_EMITS", ())
+                want_xa, want_dx = use16 and "xa" in emits, ctx.up16 and "dx" in emits
+                if want_xa or want_dx:
+                    # the apply pass has x, its statistics and dx in registers: it also writes this layer's weight-gradient operand
+                    # bf16(act(IN(x))) and the bf16 image of dx for the layer that produced x
+                    dx, dx16, xa16 = K.in_bwd_apply16(dxa, x, in_scale, in_shift, ctx.slope, sums, dx_add=dcarry,
+                                                      want_dx16=want_dx, want_xa16=want_xa)
+                    if dx16 is not None:
+                        dx._cwf16 = dx16
+                else:
+                    dx = K.in_bwd_apply(dxa, x, in_scale, in_shift, ctx.slope, sums, dx_add=dcarry)
             elif in_scale is not None:
                 K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op)
                 dx = K.in_bwd(dxa, x, in_scale, in_shift, ctx.slope, dx_add=dcarry)
@@ -253,7 +264,30 @@ class _ConvFn(torch.autograd.Function):
                     dx = K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op, residual=dcarry)
         elif dcarry is not None:
             dx = dcarry
-        return dx, dw, db, None, None, None, None, dres, None, None, None, None, None
+        if to_sink:
+            # gradient-sink path (Trainer): slabs now, ONE batched reduce per backward phase writes dW / db into the flat buffer
+            dyv = dy[..., :spec.cout] if dy.shape[-1] != spec.cout else dy
+            kw = dict(x16=xa16, dy16=dy16) if (use16 and (xa16 is not None or dy16 is not None)) else {}
+            K.wgrad_to(spec, spec.op, x, in_scale, in_shift, ctx.slope, dyv, spec.cout, spec.inv_map, sw, sb if spec.has_bias_map else None,
+                       allow_async=dy_private, **kw)
+            sink.mark(w)
+            if sb is not None:
+                if not spec.has_bias_map:   # ConvTranspose: the bias gradient spans the 8 parity classes
+                    K.stats_channel_sum(K.in_stats(dy), sb)
+                sink.mark(ctx.bias_ref)
+        elif ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dyv = dy[..., :spec.cout] if dy.shape[-1] != spec.cout else dy
+            # side-stream weight gradients only where nothing on the main stream can touch their operands or results early:
+            #  * a weight applied twice in the forward, or a .grad that already exists, makes AccumulateGrad add IN PLACE;
+            #  * with a residual, dy itself is handed on as the residual's gradient and the engine may accumulate into it
+            #    in place while the side stream still reads it (record_stream guards reuse, not modification)
+            once = spec.uses <= 1 and w.grad is None and dy_private
+            dwf, db = K.wgrad(spec.op, x, in_scale, in_shift, ctx.slope, dyv, spec.cout, spec.inv_map, spec.has_bias_map, w.numel(), w_ref_shape=w.shape,
+                              allow_async=once)
+            dw = dwf.view(w.shape)
+            if db is None:      # ConvTranspose: bias gradient spans the 8 parity classes
+                db = K.stats_channel_sum(K.in_stats(dy), torch.empty(spec.cout, dtype=torch.float32, device=dy.device))
+        return dx, dw, db, None, None, None, None, dres, None, None, None, None, None, None, None
 
 
 class _FusedConvFn(torch.autograd.Function):
@@ -310,6 +344,19 @@ def fused_conv3(x, convs, spec):
     return y, (sc, sh)
 
 
+class CarryLink:
+    """Side channel for the gradient of a carried alias (conv(..., carry=True) hands its input on as a second output; a residual
+    connection consumes it).  A conv that takes the alias as its `residual` appends dL/d(residual) -- which IS its incoming dy -- here
+    instead of returning it to autograd; the producing conv's backward collects it (and adds whatever reached the alias through
+    autograd from other consumers).  The point: dy is then referenced by this code alone, nothing can accumulate into it in place,
+    and the residual layer's weight gradient may read it from the side stream like every other layer's (before: the eight EnBlock
+    conv2 weight gradients, 1.3 ms per step, ran on the main stream)."""
+    __slots__ = ("grads",)
+
+    def __init__(self):
+        self.grads = []
+
+
 def conv(x, w, b, spec, in_norm=None, slope=1.0, residual=None, out_scale=None, want_stats=False, carry=False, out=None):
     """y = conv(act(IN(x)))(+bias)(+residual)(*out_scale).  in_norm = (scale, shift) of x or None.
     Returns (y, (scale_y, shift_y) or None), with carry=True (y, stats, x_alias): use x_alias for every further use of x
@@ -322,7 +369,15 @@ def conv(x, w, b, spec, in_norm=None, slope=1.0, residual=None, out_scale=None, 
         link.claimed = True
         if link.shared:
             link = None
-    y, s1, s2, xc = _ConvFn.apply(x, w, b, spec, sc, sh, float(slope), residual, out_scale, want_stats, carry, link, out)
+    res_link = getattr(residual, "_cwf_carry", None) if residual is not None else None
+    carry_link = CarryLink() if (carry and torch.is_grad_enabled()) else None
+    y, s1, s2, xc = _ConvFn.apply(x, w, b, spec, sc, sh, float(slope), residual, out_scale, want_stats, carry, link, out, res_link, carry_link)
+    if carry_link is not None and xc is not None:
+        xc._cwf_carry = carry_link
+    ok16 = getattr(backend(), "bf16_operands_ok", None)
+    if ok16 is not None and residual is None and out_scale is None and torch.is_grad_enabled() and \
+            ok16(spec.op, spec.cin, spec.cout, y.shape[1] * y.shape[2] * y.shape[3]):
+        y._cwf_want16 = True      # whoever computes dL/dy (an InstanceNorm-backward apply pass) adds its bf16 image (this layer's kernels take it)
     st = (s1, s2) if want_stats else None
     return (y, st, xc) if carry else (y, st)
 
@@ -423,30 +478,47 @@ class NaaLink:
 
 class _NormActAddFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, scale, shift, slope, residual, link):
+    def forward(ctx, x, scale, shift, slope, residual, link, want16):
         ctx.slope = slope
         ctx.has_res = residual is not None
         ctx.link = link
+        ctx.up16 = bool(getattr(x, "_cwf_want16", False))
         ctx.save_for_backward(x, scale, shift)
-        return backend().norm_act_add(x, scale, shift, slope, residual)
+        if want16:
+            y, y16 = backend().norm_act_add(x, scale, shift, slope, residual, want16=True)
+            ctx.mark_non_differentiable(y16)
+            return y, y16
+        return backend().norm_act_add(x, scale, shift, slope, residual), None
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _d16):
         x, scale, shift = ctx.saved_tensors
         link = ctx.link
+        K = backend()
         if link is not None and link.sums is not None and not link.shared:
             sums, link.sums = link.sums, None        # from the consuming conv's data-gradient epilogue (this backward pass)
-            dx = backend().in_bwd_apply(dy, x, scale, shift, ctx.slope, sums)
+            if ctx.up16 and "dx" in getattr(K, "APPLY_EMITS", ()):
+                dx, dx16, _ = K.in_bwd_apply16(dy, x, scale, shift, ctx.slope, sums, want_dx16=True)
+                dx._cwf16 = dx16
+            else:
+                dx = K.in_bwd_apply(dy, x, scale, shift, ctx.slope, sums)
         else:
-            dx = backend().in_bwd(dy, x, scale, shift, ctx.slope)
-        return dx, None, None, None, (dy if ctx.has_res else None), None
+            dx = K.in_bwd(dy, x, scale, shift, ctx.slope)
+        return dx, None, None, None, (dy if ctx.has_res else None), None, None
 
 
-def norm_act_add(x, stats, slope, residual=None):
+def norm_act_add(x, stats, slope, residual=None, emit16=False):
+    """emit16: the consumer of y is a full-resolution 16-channel conv without prologue -- y also leaves as a bf16 image, the operand
+    of that conv's weight gradient (HipBackend.bf16_operands_ok)."""
     link = NaaLink(x, stats[0], stats[1], float(slope)) if torch.is_grad_enabled() else None
-    y = _NormActAddFn.apply(x, stats[0], stats[1], float(slope), residual, link)
+    ok16 = getattr(backend(), "bf16_operands_ok", None)
+    want16 = bool(emit16 and torch.is_grad_enabled() and ok16 is not None and "xa" in getattr(backend(), "APPLY_EMITS", ()) and x.shape[-1] == 16 and
+                  ok16(pk.CONV3_S1, 16, 16, x.shape[1] * x.shape[2] * x.shape[3]))
+    y, y16 = _NormActAddFn.apply(x, stats[0], stats[1], float(slope), residual, link, want16)
     if link is not None:
         y._cwf_link = link                           # picked up by the conv that takes y as its (un-normalised) input
+    if y16 is not None:
+        y._cwf16x = y16
     return y
 
 

@@ -264,6 +264,58 @@ class HipBackend:
                    sums.data_ptr(), _p(dx_add), a_ldc, dx.data_ptr(), c, n, d * h * w, c, self._stream())
         return dx
 
+    # ------------------------------------------------------------------ bf16 operand images (16-channel full-resolution layers)
+    # The weight gradient of the full-resolution 16-channel 3x3x3 layers takes its operands as bf16 tensors [N,D,H,W,16] when both
+    # exist (cwf_wgrad16_bf16: LDS-DMA staging, half the bytes, no conversion): xa16 = bf16(act(IN(x))) is a side output of the
+    # layer's own InstanceNorm-backward apply pass, dy16 of the pass that produced the incoming gradient.  Same operand values as
+    # the fp32-tensor kernel computes per tile (single-bf16 products), so results do not change.
+    # which bf16 images the main-stream InstanceNorm-backward apply pass (and the block tail) write as side outputs
+    # (CWF_APPLY_EMITS="xa,dx", "" = none): each costs the main stream 2 B per element; without it a conversion pass in front of the
+    # weight gradient costs the side stream 6 B per element.  Measured (plan mode, one box, volumes/s): none 102.7, dx 104.2, xa,dx 106.2.
+    import os as _os
+    APPLY_EMITS = tuple(t for t in _os.environ.get("CWF_APPLY_EMITS", "xa,dx").split(",") if t)
+
+    def bf16_operands_ok(self, op, cin, cout, nvox):
+        import os
+        if os.environ.get("CWF_NO_BF16_OPERANDS"):
+            return False
+        return op == pk.CONV3_S1 and cin == 16 and cout == 16 and nvox >= 32768 and (_WGRAD_PRECISION or _PRECISION) == "bf16"
+
+    def zero16(self, device):
+        z = getattr(self, "_zero16", None)
+        if z is None:
+            z = self._zero16 = {}
+        device = torch.device(device)
+        t = z.get(device)
+        if t is None:
+            t = z[device] = torch.zeros(64, dtype=torch.uint8, device=device)
+        return t
+
+    def in_bwd_apply16(self, dy, x, scale, shift, slope, sums, dx_add=None, want_dx16=False, want_xa16=False, need_f32=True):
+        """in_bwd_apply with the bf16 side outputs: returns (dx, dx16, xa16).  dx16 = bf16(dx); xa16 = bf16(act(x*scale+shift)).
+        need_f32=False: dx is an UNWRITTEN carrier (nothing reads the fp32 gradient; autograd wants an fp32 tensor of x's shape)."""
+        dy, dy_ldc = cl(dy)
+        x, x_ldc = cl(x)
+        n, d, h, w, c = x.shape
+        dx = torch.empty((n, d, h, w, c), dtype=_f32, device=x.device)
+        dx16 = torch.empty((n, d, h, w, c), dtype=torch.bfloat16, device=x.device) if want_dx16 else None
+        xa16 = torch.empty((n, d, h, w, c), dtype=torch.bfloat16, device=x.device) if want_xa16 else None
+        assert need_f32 or dx16 is not None
+        a_ldc = 0
+        if dx_add is not None:
+            dx_add, a_ldc = cl(dx_add)
+        self._call("cwf_in_bwd_apply_ex", dy.data_ptr(), dy_ldc, x.data_ptr(), x_ldc, scale.data_ptr(), shift.data_ptr(), float(slope),
+                   sums.data_ptr(), _p(dx_add), a_ldc, dx.data_ptr() if need_f32 else 0, c, _p(dx16), _p(xa16), n, d * h * w, c, self._stream())
+        return dx, dx16, xa16
+
+    def to_bf16(self, x, scale=None, shift=None, slope=1.0):
+        """bf16(act(x*scale+shift)) (scale None: bf16(x)) as a [N,D,H,W,C] bfloat16 tensor -- a stream pass, for operands no producer emitted."""
+        x, x_ldc = cl(x)
+        n, d, h, w, c = x.shape
+        y = torch.empty((n, d, h, w, c), dtype=torch.bfloat16, device=x.device)
+        self._call("cwf_to_bf16", x.data_ptr(), x_ldc, _p(scale), _p(shift), float(slope), y.data_ptr(), n, d * h * w, c, self._stream())
+        return y
+
     def conv_grouped(self, x_all, cin, wpks, biases, cout, y_all, x_goff, y_goff, w_refs=None, fwd_op=None, prec=None):
         """G = len(wpks) channel-grouped 3x3x3 stride-1 convs in ONE launch (cwf_conv_mfma_bf16_grouped): group q reads channels
         [q*x_goff, q*x_goff + cin) of x_all and writes channels [q*y_goff, q*y_goff + cout) of y_all (same voxel rows).  Data
@@ -347,20 +399,22 @@ class HipBackend:
                 self._wgrad_to_impl(*args)
         self._wg_keep.extend(held)
 
-    def wgrad_to(self, key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec=None, allow_async=False):
+    def wgrad_to(self, key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec=None, x16=None, dy16=None, allow_async=False):
+        """x16 / dy16: bf16 operand images (see bf16_operands_ok).  Given one of them for an eligible layer, the other is made by a
+        conversion pass in front of the launch (on the stream the launch runs on); x / dy are then not read."""
         if self.wgrad_async and allow_async and self.wgrad_defer:
-            self._wg_held.append((key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec))
+            self._wg_held.append((key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec, x16, dy16))
             return
         if self.wgrad_async and allow_async:
             side = self.wgrad_stream(x.device)
             side.wait_stream(torch.cuda.current_stream(x.device))
             with torch.cuda.stream(side):
-                self._wgrad_to_impl(key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec)
-            for t in (x, dy, in_scale, in_shift):
+                self._wgrad_to_impl(key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec, x16, dy16)
+            for t in (x, dy, in_scale, in_shift, x16, dy16):
                 if t is not None:
                     t.record_stream(side)
         else:
-            self._wgrad_to_impl(key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec)
+            self._wgrad_to_impl(key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec, x16, dy16)
             self._wg_sync_needed = self.wgrad_async          # a main-stream producer: the side-stream reduce must wait for it
         if len(self._wg_pending) >= self.flush_every:
             # reduce in instalments: the LAST reduce of backward (after the stem's weight gradient) is exposed before the optimizer
@@ -368,11 +422,14 @@ class HipBackend:
             # the descriptor tables are keyed by their rows and must already exist when the capture runs.)
             self.wgrad_flush(x.device)
 
-    def _wgrad_to_impl(self, key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec):
+    def _wgrad_to_impl(self, key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec, x16=None, dy16=None):
         x, x_ldc = cl(x)
         dy, dy_ldc = cl(dy)
         n, di, hi, wi, cin = x.shape
         _, do, ho, wo, _ = dy.shape
+        # eligible layers always take the bf16-image kernel; an image nobody handed over is made here, i.e. on the stream this launch
+        # runs on (normally the side stream, which has slack: the main stream's kernels are the step's critical path)
+        use16 = prec is None and self.bf16_operands_ok(op, cin, cout, do * ho * wo)
         nsplit = self.lib.cwf_wgrad_nsplit(op, n, do, ho, wo, cin, cout)
         slab = self.lib.cwf_wgrad_slab_floats(op, cin, cout)
         if nsplit <= 0 or slab <= 0 or slab != inv_map.numel():
@@ -383,7 +440,18 @@ class HipBackend:
             part = torch.empty(int(nsplit * slab), dtype=_f32, device=x.device)
             self._wg_part[pk_] = part
         mode = prec or _WGRAD_PRECISION or _PRECISION
-        if mode == "fp32":
+        if use16:
+            if x16 is None:
+                x16 = self.to_bf16(x, in_scale, in_shift, slope)
+            if dy16 is None:
+                dy16 = self.to_bf16(dy)
+            assert x16.dtype == torch.bfloat16 and dy16.dtype == torch.bfloat16 and x16.is_contiguous() and dy16.is_contiguous()
+            assert tuple(x16.shape) == (n, di, hi, wi, 16) and tuple(dy16.shape) == (n, do, ho, wo, 16)
+            used = ctypes.c_int(0)
+            self._call("cwf_wgrad16_bf16", x16.data_ptr(), dy16.data_ptr(), self.zero16(x.device).data_ptr(), part.data_ptr(),
+                       n, di, hi, wi, ctypes.addressof(used), self._stream())
+            nsplit = used.value
+        elif mode == "fp32":
             self._call("cwf_wgrad_mfma", op, x.data_ptr(), x_ldc, _p(in_scale), _p(in_shift), float(slope),
                        dy.data_ptr(), dy_ldc, part.data_ptr(), n, di, hi, wi, cin, do, ho, wo, cout, self._stream())
         else:
@@ -523,16 +591,18 @@ class HipBackend:
         self._call("cwf_in_stats", x.data_ptr(), ldc, stats.data_ptr(), n, d * h * w, c, self._stream())
         return stats
 
-    def norm_act_add(self, x, scale, shift, slope, residual=None):
+    def norm_act_add(self, x, scale, shift, slope, residual=None, want16=False):
+        """want16: also returns bf16(y) (the operand image of a consuming layer's weight gradient): (y, y16)"""
         x, ldc = cl(x)
         n, d, h, w, c = x.shape
         y = torch.empty((n, d, h, w, c), dtype=_f32, device=x.device)
+        y16 = torch.empty((n, d, h, w, c), dtype=torch.bfloat16, device=x.device) if want16 else None
         r_ldc = 0
         if residual is not None:
             residual, r_ldc = cl(residual)
-        self._call("cwf_norm_act_add", x.data_ptr(), ldc, scale.data_ptr(), shift.data_ptr(), float(slope), _p(residual), r_ldc,
-                   y.data_ptr(), c, n, d * h * w, c, self._stream())
-        return y
+        self._call("cwf_norm_act_add_ex", x.data_ptr(), ldc, scale.data_ptr(), shift.data_ptr(), float(slope), _p(residual), r_ldc,
+                   y.data_ptr(), c, _p(y16), n, d * h * w, c, self._stream())
+        return (y, y16) if want16 else y
 
     def in_bwd(self, dy, x, scale, shift, slope, dx_add=None):
         """dx for y = act(IN(x)) given dy = dL/dy (full InstanceNorm backward, statistics included)."""

@@ -91,9 +91,10 @@ class Trainer:
         # stream idles 1.7 ms per step -- instead of competing with the decoder's own HBM-bound data gradients (95.6 -> 96.7
         # volumes/s; neutral while the step was still bound elsewhere).  CWF_DEFER_WGRAD=0 launches them immediately.
         # Level 2 also holds the heads / couplers / decouplers phase's ~40 small weight-gradient launches until backward is in the
-        # encoder.  Round 3 (launch plan: the host is never the bound): level 2 is the default there (103.1 -> 104.8 volumes/s with 128
-        # side workgroups); launches from Python keep level 1.
-        self.defer_level = int(os.environ.get("CWF_DEFER_WGRAD", "2" if self.graph_mode == "plan" else "1"))
+        # encoder.  Round 3, launch plan (the host is never the bound): level 2 was best (103.1 -> 104.8 volumes/s with 128 side
+        # workgroups) while the eight residual layers' weight gradients still ran on the main stream; with them on the side stream
+        # (functional.CarryLink) the SIDE stream ends the step, and it must start earlier: level 1 (0 / 1 / 2: 104.0 / 106.2 / 100.5).
+        self.defer_level = int(os.environ.get("CWF_DEFER_WGRAD", "1"))
         self.defer_decoder_wgrad = self.defer_level >= 1
 
     # ------------------------------------------------------------------------------------------------

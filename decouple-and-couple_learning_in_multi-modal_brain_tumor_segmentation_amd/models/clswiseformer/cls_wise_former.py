@@ -224,10 +224,11 @@ class EnBlock2(nn.Module):
         self.conv1 = HipConv(in_channels, in_channels)
         self.conv2 = HipConv(in_channels, in_channels)
 
-    def forward(self, x):
+    def forward(self, x, emit16=False):
         h, hs, xc = self.conv1(x, want_stats=True, carry=True)        # the residual's gradient is folded into conv1's dgrad epilogue
         g, gs = self.conv2(h, in_norm=hs, slope=0.01, want_stats=True)
-        return CF.norm_act_add(g, gs, 0.01, residual=xc)
+        # emit16: the next block's conv1 reads this output without a prologue -- its weight gradient takes the bf16 image written here
+        return CF.norm_act_add(g, gs, 0.01, residual=xc, emit16=emit16)
 
 
 class DeBlock(EnBlock2):
@@ -274,7 +275,7 @@ class Decoder(nn.Module):
         x8 = self.Enblock8_2(self.Enblock8_1(x8))
         y4 = self.DeBlock4_1(self.DeBlock4(self.DeUp4(x8, x3_1)))
         y3 = self.DeBlock3_1(self.DeBlock3(self.DeUp3(y4, x2_1)))
-        y2 = self.DeBlock2_1(self.DeBlock2(self.DeUp2(y3, x1_1)))
+        y2 = self.DeBlock2_1(self.DeBlock2(self.DeUp2(y3, x1_1), emit16=True))
         logits, _ = self.endconv(y2)
         if aux is not None:
             aux["logits"] = logits.permute(0, 4, 1, 2, 3)

@@ -156,6 +156,27 @@ int cwf_in_bwd_apply(const float* dy, int dy_ldc, const float* x, int x_ldc, con
                      float slope, const double* sums, const float* dx_add, int a_ldc, float* dx, int dx_ldc,
                      int N, int64_t V, int C, void* stream);
 
+/* cwf_in_bwd_apply with bf16 side outputs (each nullable; dx or dx16 must be given):
+ *   dx16 [N*V][C] bf16 = bf16(dx)                 -- the gradient image the 16-channel weight-gradient kernel below takes
+ *   xa16 [N*V][C] bf16 = bf16(act(x*scale+shift)) -- the activated input of the layer whose backward this is, i.e. the x operand of
+ *                                                   its weight gradient (convolution_backward's `input`, Unet_skipconnection.py:39-56) */
+int cwf_in_bwd_apply_ex(const float* dy, int dy_ldc, const float* x, int x_ldc, const float* scale, const float* shift,
+                        float slope, const double* sums, const float* dx_add, int a_ldc, float* dx, int dx_ldc,
+                        void* dx16, void* xa16, int N, int64_t V, int C, void* stream);
+/* cwf_norm_act_add that also writes y16 [N*V][C] bf16 = bf16(y) (nullable) */
+int cwf_norm_act_add_ex(const float* x, int x_ldc, const float* scale, const float* shift, float slope,
+                        const float* residual, int r_ldc, float* y, int y_ldc, void* y16, int N, int64_t V, int C, void* stream);
+/* y16 [N*V][C] bf16 = bf16(act(x*scale+shift))  (scale == NULL: bf16(x)) */
+int cwf_to_bf16(const float* x, int x_ldc, const float* scale, const float* shift, float slope, void* y16,
+                int N, int64_t V, int C, void* stream);
+/* Weight / bias gradient slabs of a 3x3x3 stride-1 16 -> 16 conv (padding 1) from bf16 operand images (single-bf16 products, fp32
+ * accumulate): xa16 = bf16(act(IN(x))) [N][D][H][W][16], dy16 [N][D][H][W][16], zero16 = 16 zero bytes (the padding source of the
+ * LDS-DMA loaders).  Slab layout and reduction: cwf_wgrad_mfma_bf16(CWF_CONV3_S1, 16, 16) / cwf_wgrad_reduce.
+ * Replaces the weight half of aten::convolution_backward for EnBlock1 / EnBlock1_1 / DeBlock2 / DeBlock2_1 (Unet_skipconnection.py:36-57,
+ * cls_wise_former.py:732-754). */
+int cwf_wgrad16_bf16(const void* xa16, const void* dy16, const void* zero16, float* partial,
+                     int N, int D, int H, int W, int* nsplit_used, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K6/K7  token path: LayerNorm, Linear (strided batched MFMA GEMM), softmax rows, GELU
  *        ResidualNorm.py:4-47, SelfAttention.py:74-102

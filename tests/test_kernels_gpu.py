@@ -152,6 +152,81 @@ def test_fused_norm_backward_sums(hip, op, cin, cout, size, n, prec):
     close(dx_fused, dx_two_pass.cpu(), rtol=2e-5, what="fused norm backward")
 
 
+def _bf16_rne(t):
+    """round-to-nearest-even bf16 of an fp32 tensor (what v_cvt_pk_bf16_f32 does)"""
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("size,n", [((64, 64, 64), 2), ((34, 38, 50), 1), ((32, 32, 32), 1)])
+def test_bf16_operand_images_and_dma_weight_gradient(hip, size, n):
+    """Round 3: the full-resolution 16-channel weight gradient on bf16 operand images (cwf_wgrad16_bf16, LDS-DMA staging).
+    (a) cwf_in_bwd_apply_ex: dx bit-equal to cwf_in_bwd_apply, dx16 = bf16(dx), xa16 = bf16(act(IN(x))) -- with and without the
+        fp32 output; cwf_norm_act_add_ex / cwf_to_bf16 likewise.
+    (b) the DMA kernel's dW / db equal the fp32-tensor kernel's (same single-bf16 operand values: tolerance = summation order only),
+        both against the oracle (kernel_emul wgrad) within the single-bf16 tolerance; ragged tiles and borders included."""
+    from cwf import functional as CF, kernels
+    d, h, w_ = size
+    c = 16
+    x = rnd(n, d, h, w_, c, seed=21)
+    g = rnd(n, d, h, w_, c, seed=22)
+    add = rnd(n, d, h, w_, c, seed=23)
+    sc = rnd(n, c, seed=24).abs() + 0.5
+    sh = rnd(n, c, seed=25)
+    xd, gd, ad, scd, shd = x.to(DEV), g.to(DEV), add.to(DEV), sc.to(DEV), sh.to(DEV)
+    sums = hip.in_stats(gd)                       # any (N, C, 2) doubles will do for the apply formula
+    for slope in (0.0, 0.01):
+        dx_ref = hip.in_bwd_apply(gd, xd, scd, shd, slope, sums, dx_add=ad)
+        dx, dx16, xa16 = hip.in_bwd_apply16(gd, xd, scd, shd, slope, sums, dx_add=ad, want_dx16=True, want_xa16=True)
+        assert torch.equal(dx, dx_ref)
+        assert torch.equal(dx16, _bf16_rne(dx_ref))
+        hh = torch.addcmul(shd[:, None, None, None, :], xd, scd[:, None, None, None, :])     # (fma: the kernel's fmaf)
+        xa_ref = torch.maximum(hh, hh * slope)
+        # the host formula may differ from the kernel's fma in the last bit before rounding: compare in bf16 ulps
+        diff = (xa16.float() - _bf16_rne(xa_ref).float()).abs()
+        assert float((diff > 0).float().mean()) < 1e-3 and float(diff.max()) <= float(xa_ref.abs().max()) * 2 ** -7
+        assert torch.equal(xa16, hip.to_bf16(xd, scd, shd, slope))
+        _, dx16b, _ = hip.in_bwd_apply16(gd, xd, scd, shd, slope, sums, dx_add=ad, want_dx16=True, need_f32=False)
+        assert torch.equal(dx16b, dx16)
+    y_ref = hip.norm_act_add(gd, scd, shd, 0.01, ad)
+    y, y16 = hip.norm_act_add(gd, scd, shd, 0.01, ad, want16=True)
+    assert torch.equal(y, y_ref) and torch.equal(y16, _bf16_rne(y_ref))
+    assert torch.equal(hip.to_bf16(gd), _bf16_rne(gd))
+
+    # ---- weight gradient
+    spec = CF.ConvSpec(pk.CONV3_S1, c, c).to(torch.device(DEV))
+    wn = c * c * 27
+    kernels.set_precision("bf16x3", wgrad="bf16", dgrad="bf16")
+    try:
+        assert hip.bf16_operands_ok(pk.CONV3_S1, c, c, d * h * w_) == (d * h * w_ >= 32768)
+        dw_a = torch.zeros(wn, device=DEV); db_a = torch.zeros(c, device=DEV)
+        dw_b = torch.zeros(wn, device=DEV); db_b = torch.zeros(c, device=DEV)
+        dw_c = torch.zeros(wn, device=DEV); db_c = torch.zeros(c, device=DEV)
+        import os
+        os.environ["CWF_NO_BF16_OPERANDS"] = "1"                                                                   # the fp32-tensor kernel
+        try:
+            hip.wgrad_to("t16a", pk.CONV3_S1, xd, scd, shd, 0.01, gd, c, spec.inv_map, dw_a, db_a)
+            hip.wgrad_flush(torch.device(DEV))
+        finally:
+            del os.environ["CWF_NO_BF16_OPERANDS"]
+        xa16 = hip.to_bf16(xd, scd, shd, 0.01)
+        hip.wgrad_to("t16b", pk.CONV3_S1, xd, scd, shd, 0.01, gd, c, spec.inv_map, dw_b, db_b, x16=xa16, dy16=hip.to_bf16(gd))
+        hip.wgrad_flush(torch.device(DEV))
+        hip.wgrad_to("t16c", pk.CONV3_S1, xd, scd, shd, 0.01, gd, c, spec.inv_map, dw_c, db_c)                          # both images made inside
+        hip.wgrad_flush(torch.device(DEV))
+    finally:
+        kernels.set_precision("fp32")
+    torch.cuda.synchronize()
+    if d * h * w_ >= 32768:
+        close(dw_b, dw_a.cpu(), rtol=2e-5, what="dma wgrad vs fp32-tensor wgrad")
+        close(db_b, db_a.cpu(), rtol=2e-5, what="dma bgrad vs fp32-tensor bgrad")
+    else:
+        assert torch.equal(dw_b, dw_a)            # not eligible: the same (fp32-tensor) kernel ran
+    assert torch.equal(dw_c, dw_b) and torch.equal(db_c, db_b)
+    gw_ref, gb_ref = E.wgrad(pk.CONV3_S1, x, sc, sh, 0.01, g, c, None, True, wn, w_ref_shape=(c, c, 3, 3, 3))
+    close(dw_b, gw_ref, rtol=PREC_TOL["bf16"], what="dma wgrad vs oracle")
+    close(db_b, gb_ref, rtol=PREC_TOL["bf16"], what="dma bgrad vs oracle")
+
+
 @pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("cin,cout,size,n", [
     (32, 32, (16, 16, 32), 2),       # 64 tiles, two samples: 32 workgroups x one round
