@@ -21,6 +21,8 @@ struct ConvArgsB {
   // own packed weights and bias; blockIdx.z = (group * N + n) * ncls + class.  groups == 0: an ordinary launch.
   int groups, x_goff, y_goff;
   const uint4* wpk_g[3]; const float* bias_g[3];
+  // conv16s, IN16 instantiation: the input as a bf16 image (16-byte granules, two per voxel) and the 16-byte zero page of its loaders
+  const uint4* x16; const uint4* zero16;
 };
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));

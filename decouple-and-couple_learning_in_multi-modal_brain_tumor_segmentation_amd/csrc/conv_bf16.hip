@@ -835,12 +835,18 @@ __global__ __launch_bounds__(512) void conv16_kernel(const ConvArgsB a, int tota
 struct C16sWork { int nseg, seg_len, hsplit, ncols; };
 static int g_conv16_diag_mode = 0;                   // diagnostics (cwf_debug_conv16_mode): 1 no stores, 2 no loads, 8 no epilogue
 
-template <bool X3, bool DIAG>
+// IN16 = true (single-bf16 data-gradient launches whose input gradient exists as a bf16 image, [N][D][H][W][16]): the loader waves
+// convert nothing -- they issue LDS-DMA pieces (global_load_lds_dwordx4, 1 KiB of LDS each; zero padding = a 16-byte zero page) and the
+// ring has FOUR row groups per plane (16 rows) so that two elements stay in flight while a tile reads one and a half groups.
+template <bool X3, bool DIAG, bool IN16 = false>
 __global__ __launch_bounds__(512) void conv16s_kernel(const ConvArgsB a, const C16sWork wk) {
+  static_assert(!(IN16 && X3), "the bf16 input image is a single-bf16 operand");
+  constexpr int RH = IN16 ? 16 : C16_RH;               // ring rows per plane
+  constexpr int NPH = RH / 4;                          // ring groups = compile-time phases of the tile loop
   extern __shared__ float4 lds4[];
   const ConvGeom& g = a.g;
   constexpr int ROWB = C16_IW * 32;                    // bytes of one LDS row (18 voxels x 16 ch bf16)
-  constexpr int PLANEB = C16_RH * ROWB;                // one plane of the ring
+  constexpr int PLANEB = RH * ROWB;                   // one plane of the ring
   constexpr int IMGB = C16_ID * PLANEB;                // one image (hi or lo): 41,472 B
   unsigned short* lds = reinterpret_cast<unsigned short*>(lds4);
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds4;
@@ -886,7 +892,7 @@ __global__ __launch_bounds__(512) void conv16s_kernel(const ConvArgsB a, const C
     const unsigned b_kw = bl + (second ? 32u : 0u);                      // (kw0, kw1) pairs
     const unsigned b_pl = bl + (second ? (unsigned)PLANEB : 0u);         // (kd0, kd1) pairs
     const unsigned b_up = bl + (second ? (unsigned)ROWB : 0u);           // (kh0, kh1) pair, next slot
-    const unsigned b_wr = bl + (second ? 0u : (unsigned)(11 * ROWB));    // (kh0, kh1) pair across the ring wrap (slot 11 -> 0): the
+    const unsigned b_wr = bl + (second ? 0u : (unsigned)((RH - 1) * ROWB));    // (kh0, kh1) pair across the ring wrap (slot 11 -> 0): the
                                                                          // immediate addresses the SECOND tap's row, first lanes add 11 rows
     const float bv = (a.bias && r < g.Cout) ? a.bias[r] : 0.f;
     const f32x4 bias4 = {bv, bv, bv, bv};
@@ -943,15 +949,15 @@ __global__ __launch_bounds__(512) void conv16s_kernel(const ConvArgsB a, const C
         const int kd = ta / 9, kh = (ta / 3) % 3, kw = ta % 3;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          const int slot = (4 * PH + 10 + m + kh) % C16_RH;             // first tap's row slot (rows 0,1 of the tile: previous group)
+          const int slot = (4 * PH + RH - 2 + m + kh) % RH;             // first tap's row slot (rows 0,1 of the tile: previous group)
           unsigned base; int imm;
-          if (s_ < 9) { base = b_kw; imm = (kd * C16_RH + slot) * ROWB + kw * 32; }
-          else if (s_ < 12) { base = b_pl; imm = (kd * C16_RH + slot) * ROWB + kw * 32; }
+          if (s_ < 9) { base = b_kw; imm = (kd * RH + slot) * ROWB + kw * 32; }
+          else if (s_ < 12) { base = b_pl; imm = (kd * RH + slot) * ROWB + kw * 32; }
           else if (s_ == 12) {
-            const int slot2 = (slot + 1) % C16_RH;
-            if (slot2 == slot + 1) { base = b_up; imm = (kd * C16_RH + slot) * ROWB + kw * 32; }
-            else { base = b_wr; imm = (kd * C16_RH + slot2) * ROWB + kw * 32; }        // wrap: immediate = second tap's row (slot 0)
-          } else { base = bl; imm = (kd * C16_RH + slot) * ROWB + kw * 32; }
+            const int slot2 = (slot + 1) % RH;
+            if (slot2 == slot + 1) { base = b_up; imm = (kd * RH + slot) * ROWB + kw * 32; }
+            else { base = b_wr; imm = (kd * RH + slot2) * ROWB + kw * 32; }        // wrap: immediate = second tap's row (slot 0)
+          } else { base = bl; imm = (kd * RH + slot) * ROWB + kw * 32; }
           fa[b_][m] = *(lds_u4p)(uintptr_t)(base + (unsigned)imm);
           if (X3) fl[b_][m] = *(lds_u4p)(uintptr_t)(base + (unsigned)(imm + IMGB));
         }
@@ -1097,14 +1103,66 @@ __global__ __launch_bounds__(512) void conv16s_kernel(const ConvArgsB a, const C
       asm volatile("s_barrier" ::: "memory");            // pre-tile: loader only
       ++u;
       for (int t = 0; t < sg.len; ++t, ++u) {
-        const int ph = u % 3;
+        const int ph = u % NPH;
         if (ph == 0) tile(std::integral_constant<int, 0>{}, sg, t);
         else if (ph == 1) tile(std::integral_constant<int, 1>{}, sg, t);
-        else tile(std::integral_constant<int, 2>{}, sg, t);
+        else if (NPH == 3 || ph == 2) tile(std::integral_constant<int, 2>{}, sg, t);
+        else tile(std::integral_constant<int, NPH - 1>{}, sg, t);
       }
     }
     if (pend == 1) drain(std::true_type{}); else if (pend == 2) drain(std::false_type{});
     if (a.stats) flush_stats(stat_n);
+  } else if constexpr (IN16) {
+    // =============================================================== loader waves, bf16 input image: LDS-DMA only
+    // Element (k, e) (e = 0: the segment's pre-tile) brings 6 planes x 4 new rows x 18 voxels x 32 B: per plane one contiguous
+    // 2,304-B block of the ring = 144 granules of 16 B = pieces of 64 + 64 + 16 lanes.  Wave lw takes planes lw, lw + 4.
+    // Element u lands in ring group u % 4.  Tile u reads groups u - 1 (its last two rows) and u, elements u + 1 and u + 2 are in
+    // flight: element it + 2 is issued right after barrier `it` (group it + 2 was last read by tile it - 1, which every MFMA wave
+    // finished before that barrier), and before barrier `it` this wave waits for its pieces of element `it` (counted vmcnt).
+    const int lw = wave - 4;
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef __attribute__((address_space(1))) const void* glb_vp;
+    struct It { int k, e; };
+    auto next = [&](It it) __attribute__((always_inline)) { It o = it; if (it.e < seg_of(it.k).len) o.e = it.e + 1; else { o.k = it.k + 1; o.e = 0; } return o; };
+    int niter = 0;
+    for (int k = 0; k < nk; ++k) niter += seg_of(k).len + 1;
+    auto run = [&](auto NPL_) __attribute__((always_inline)) {
+      constexpr int NPL = decltype(NPL_)::value, NI = 3 * NPL;
+      int off[NI]; unsigned crd[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int pl = lw + 4 * (j / 3), gi = 64 * (j % 3) + lane;
+        const int r4 = gi / 36, gr = gi % 36, w = gr >> 1, half = gr & 1;
+        off[j] = ((pl * g.Hi + r4) * g.Wi + w) * 2 + half;
+        crd[j] = (unsigned)pl | ((unsigned)r4 << 3) | ((unsigned)w << 6) | (gi < 144 ? 1u << 11 : 0u);
+      }
+      auto issue = [&](It it, int u) __attribute__((always_inline)) {
+        const Seg sgm = seg_of(it.k);
+        const int id0 = sgm.tile_d * C16_TD - 1, ih0 = (sgm.th0 + it.e - 1) * C16_TH + 1, iw0 = sgm.tile_w * 16 - 1;
+        const int64_t v0 = (((int64_t)sgm.n * g.Di + id0) * g.Hi + ih0) * g.Wi + iw0;
+        const unsigned lgrp = lds_base + (unsigned)((u & 3) * 4 * ROWB);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int pl = lw + 4 * (j / 3);                 // (wave-uniform)
+          if ((crd[j] >> 11) != 0u) {                      // piece 2 of a plane: 16 lanes (the DMA writes LDS for active lanes only)
+            const int gd = id0 + (int)(crd[j] & 7u), gh = ih0 + (int)((crd[j] >> 3) & 7u), gw = iw0 + (int)((crd[j] >> 6) & 31u);
+            const bool ok = (unsigned)gd < (unsigned)g.Di && (unsigned)gh < (unsigned)g.Hi && (unsigned)gw < (unsigned)g.Wi;
+            const uint4* src = ok ? a.x16 + v0 * 2 + off[j] : a.zero16;
+            __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(uintptr_t)(lgrp + (unsigned)(pl * PLANEB + (j % 3) * 1024)), 16, 0, 0);
+          }
+        }
+      };
+      It ti{0, 0};
+      issue(ti, 0); ti = next(ti);
+      if (niter > 1) { issue(ti, 1); ti = next(ti); }
+      for (int it = 0; it < niter; ++it) {
+        if (it + 1 < niter) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");          // element `it` handed over
+        if (it + 2 < niter) { issue(ti, it + 2); ti = next(ti); }
+      }
+    };
+    if (lw < 2) run(std::integral_constant<int, 2>{}); else run(std::integral_constant<int, 1>{});
   } else {
     // =============================================================== loader waves
     const int lt = tid - 256;
@@ -1121,7 +1179,7 @@ __global__ __launch_bounds__(512) void conv16s_kernel(const ConvArgsB a, const C
       const int v = (lt >> 2) + 64 * i;
       const int pl = v / 72, r4 = (v % 72) / 18, w = v % 18;
       rel[i] = (pl * HW + r4 * g.Wi + w) * g.x_ldc + c;
-      lrel[i] = (unsigned)((pl * C16_RH + r4) * ROWB + w * 32 + q * 8);
+      lrel[i] = (unsigned)((pl * RH + r4) * ROWB + w * 32 + q * 8);
     }
     const bool last_ok = (lt >> 2) + 64 * (C16S_SLOTS - 1) < 432;
     const unsigned full_mask = last_ok ? ((1u << C16S_SLOTS) - 1u) : ((1u << (C16S_SLOTS - 1)) - 1u);
@@ -1243,7 +1301,7 @@ __global__ __launch_bounds__(512) void conv16s_kernel(const ConvArgsB a, const C
   }
 }
 
-template <bool X3>
+template <bool X3, bool IN16 = false>
 static int launch_conv16s(const ConvArgsB& a, hipStream_t st) {
   const ConvGeom& g = a.g;
   C16sWork wk;
@@ -1254,16 +1312,17 @@ static int launch_conv16s(const ConvArgsB& a, hipStream_t st) {
   wk.seg_len = (g.tiles_h + hsplit - 1) / hsplit;
   wk.hsplit = (g.tiles_h + wk.seg_len - 1) / wk.seg_len;
   wk.nseg = wk.ncols * wk.hsplit;
-  const size_t lds = (size_t)2 * C16_ID * C16_RH * C16_IW * 32 + (X3 ? 14 * 64 * 16 : 0);   // hi + lo rings (+ lo weights)
+  const size_t lds = IN16 ? (size_t)C16_ID * 16 * C16_IW * 32                                    // hi ring of 16 rows
+                          : (size_t)2 * C16_ID * C16_RH * C16_IW * 32 + (X3 ? 14 * 64 * 16 : 0);   // hi + lo rings (+ lo weights)
   int grid = 256; while (grid > 8 && grid > wk.nseg) grid -= 8;
   ConvArgsB aa = a; aa.diag = nullptr; aa.diag_mode = g_conv16_diag_mode;
   // the product kernel has no diagnostic branches; cwf_debug_conv16_mode (tools/) selects the ablation instantiation
   auto go = [&](auto D) {
     constexpr bool DG = decltype(D)::value;
-    CWF_MAX_LDS_ONCE((&conv16s_kernel<X3, DG>));
-    hipLaunchKernelGGL((conv16s_kernel<X3, DG>), dim3(grid), dim3(512), lds, st, aa, wk);
+    CWF_MAX_LDS_ONCE((&conv16s_kernel<X3, DG, IN16>));
+    hipLaunchKernelGGL((conv16s_kernel<X3, DG, IN16>), dim3(grid), dim3(512), lds, st, aa, wk);
   };
-  if (g_conv16_diag_mode) go(std::true_type{}); else go(std::false_type{});
+  if (g_conv16_diag_mode && !IN16) go(std::true_type{}); else go(std::false_type{});
   CWF_LAUNCH_CHECK();
   return 0;
 }
@@ -1621,11 +1680,41 @@ extern "C" int cwf_conv_mfma_bf16(int op, int x3, const float* x, int x_ldc, con
                                nullptr, 0, nullptr, nullptr, 1.f, N, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, stream);
 }
 
+static int conv_bf16_impl(int op, int x3, const float* x, int x_ldc, const void* wpk16, const float* bias,
+                          float* y, int y_ldc, const float* in_scale, const float* in_shift, float in_slope,
+                          const float* residual, int r_ldc, const float* out_scale, double* stats,
+                          const float* nb_x, int nb_ldc, const float* nb_scale, const float* nb_shift, float nb_slope,
+                          int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, void* stream,
+                          const void* x16, const void* zero16);
+
 extern "C" int cwf_conv_mfma_bf16_nb(int op, int x3, const float* x, int x_ldc, const void* wpk16, const float* bias,
                                      float* y, int y_ldc, const float* in_scale, const float* in_shift, float in_slope,
                                      const float* residual, int r_ldc, const float* out_scale, double* stats,
                                      const float* nb_x, int nb_ldc, const float* nb_scale, const float* nb_shift, float nb_slope,
                                      int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, void* stream) {
+  return conv_bf16_impl(op, x3, x, x_ldc, wpk16, bias, y, y_ldc, in_scale, in_shift, in_slope, residual, r_ldc, out_scale, stats,
+                        nb_x, nb_ldc, nb_scale, nb_shift, nb_slope, N, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, stream, nullptr, nullptr);
+}
+
+// The same conv with its INPUT given as a bf16 image x16 [N][Di][Hi][Wi][16] (single-bf16 operand launches of the 3x3x3 stride-1
+// 16 -> 16 full-resolution layers without prologue, i.e. their data gradients: x16 = the bf16 image of dy that the producer of dy wrote,
+// cwf_in_bwd_apply_ex).  x (fp32) is not read and may be NULL.  zero16: 16 zero bytes (padding source of the LDS-DMA loaders).
+extern "C" int cwf_conv_mfma_bf16_in16(int op, const void* x16, const void* zero16, const void* wpk16, const float* bias,
+                                       float* y, int y_ldc, const float* residual, int r_ldc, double* stats,
+                                       const float* nb_x, int nb_ldc, const float* nb_scale, const float* nb_shift, float nb_slope,
+                                       int N, int D, int H, int W, void* stream) {
+  if (!x16 || !zero16 || ((uintptr_t)x16 & 15) || ((uintptr_t)zero16 & 15)) return CWF_E_BADARG;
+  if (op != CWF_CONV3_S1 || (int64_t)D * H * W < 32768 || (int64_t)N * D * H * W >= (1ll << 30)) return CWF_E_BADARG;
+  return conv_bf16_impl(op, 0, reinterpret_cast<const float*>(x16), 16, wpk16, bias, y, y_ldc, nullptr, nullptr, 1.f, residual, r_ldc, nullptr, stats,
+                        nb_x, nb_ldc, nb_scale, nb_shift, nb_slope, N, D, H, W, 16, D, H, W, 16, stream, x16, zero16);
+}
+
+static int conv_bf16_impl(int op, int x3, const float* x, int x_ldc, const void* wpk16, const float* bias,
+                          float* y, int y_ldc, const float* in_scale, const float* in_shift, float in_slope,
+                          const float* residual, int r_ldc, const float* out_scale, double* stats,
+                          const float* nb_x, int nb_ldc, const float* nb_scale, const float* nb_shift, float nb_slope,
+                          int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, void* stream,
+                          const void* x16, const void* zero16) {
   if (!x || !wpk16 || !y || N <= 0 || Cin <= 0 || Cout <= 0) return CWF_E_BADARG;
   if (nb_x && (!stats || !nb_scale || !nb_shift || nb_ldc < Cout)) return CWF_E_BADARG;
   if ((Cin & 3) || (x_ldc & 3) || x_ldc < Cin || y_ldc < Cout) return CWF_E_ALIGN;
@@ -1648,8 +1737,17 @@ extern "C" int cwf_conv_mfma_bf16_nb(int op, int x3, const float* x, int x_ldc, 
   a.nb_x = nb_x; a.nb_ldc = nb_ldc; a.nb_scale = nb_scale; a.nb_shift = nb_shift; a.nb_slope = nb_slope;
   a.diag = nullptr; a.diag_mode = 0;
   a.groups = 0; a.x_goff = 0; a.y_goff = 0;
+  a.x16 = reinterpret_cast<const uint4*>(x16); a.zero16 = reinterpret_cast<const uint4*>(zero16);
   for (int q = 0; q < 3; ++q) { a.wpk_g[q] = nullptr; a.bias_g[q] = nullptr; }
   hipStream_t st = cwf_stream(stream);
+  if (x16) {                                           // (cwf_conv_mfma_bf16_in16 has checked the layer)
+    int nat[27];
+    for (int t = 0; t < 27; ++t) nat[t] = a.g.tapofs[t];
+    for (int t = 0; t < 27; ++t) a.g.tapofs[t] = nat[c16_tap(t)];
+    rc = cwf_build_geom(a.g, op, N, Di, Hi, Wi, Cin, x_ldc, Do, Ho, Wo, Cout, y_ldc, 16);
+    if (rc) return rc;
+    return launch_conv16s<false, true>(a, st);
+  }
   {
     int ks, nt;
     if (pw_eligible(op, a, &ks, &nt)) {                   // 1x1x1 / ConvTranspose streams: no LDS staging (pw_conv_kernel)
@@ -1702,6 +1800,7 @@ extern "C" int cwf_conv_mfma_bf16_grouped(int op, int x3, const float* x, int x_
   a.nb_x = nullptr; a.nb_ldc = 0; a.nb_scale = nullptr; a.nb_shift = nullptr; a.nb_slope = 1.f;
   a.diag = nullptr; a.diag_mode = 0;
   a.groups = groups; a.x_goff = x_goff; a.y_goff = y_goff;
+  a.x16 = nullptr; a.zero16 = nullptr;
   for (int q = 0; q < 3; ++q) {
     a.wpk_g[q] = q < groups ? reinterpret_cast<const uint4*>(wpk16[q]) : nullptr;
     a.bias_g[q] = (q < groups && bias) ? bias[q] : nullptr;

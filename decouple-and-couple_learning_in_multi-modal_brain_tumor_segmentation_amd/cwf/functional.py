@@ -187,7 +187,7 @@ class _ConvFn(torch.autograd.Function):
         ok16 = getattr(K, "bf16_operands_ok", None)
         ctx.use16 = bool(ok16 is not None and ok16(spec.op, spec.cin, spec.cout, y.shape[1] * y.shape[2] * y.shape[3]))
         ctx.x16 = getattr(x, "_cwf16x", None) if (ctx.use16 and in_scale is None) else None     # bf16(x) from x's producer (a block tail)
-        ctx.up16 = bool(getattr(x, "_cwf_want16", False))     # x's producer is such a layer: hand its gradient on with a bf16 image
+        ctx.up16 = getattr(x, "_cwf_want16", False)     # x's producer is such a layer: hand its gradient on with a bf16 image ("only": nothing else)
         ctx.save_for_backward(x, w, in_scale, in_shift, out_scale)
         # carry: x is handed on as a second output (an alias).  Whatever consumes that alias (a residual connection, a skip
         # connection) sends its gradient back HERE, where it is folded into the kernel that writes dx (dx_add of the
@@ -213,7 +213,7 @@ class _ConvFn(torch.autograd.Function):
         x, w, in_scale, in_shift, out_scale = ctx.saved_tensors
         spec = ctx.spec
         if out_scale is not None:
-            dy = K.channel_scale(dy, out_scale)
+            dy = K.channel_scale(_dy_f32(K, dy), out_scale)
         dres = dy if ctx.has_res else None
         dy_private = not ctx.has_res
         if ctx.has_res and ctx.res_link is not None:
@@ -228,25 +228,37 @@ class _ConvFn(torch.autograd.Function):
         sb = sink.view(ctx.bias_ref) if (sw is not None and ctx.bias_ref is not None) else None
         to_sink = sw is not None and (ctx.bias_ref is None or sb is not None)
         use16 = ctx.use16 and to_sink and out_scale is None
-        dy16 = getattr(dy, "_cwf16", None) if use16 else None
+        dy16 = getattr(dy, "_cwf16", None) if out_scale is None else None
+        dg16 = dy16 if (dy16 is not None and getattr(K, "bf16_dgrad_ok", lambda *a: False)(
+            spec.op, spec.cin, spec.cout, dy.shape[1] * dy.shape[2] * dy.shape[3])) else None     # the data gradient reads the bf16 image
+        if getattr(dy, "_cwf_f32_missing", False) and not (use16 and dy16 is not None and (dg16 is not None or not ctx.needs_input_grad[0])
+                                                           and not ctx.has_res):
+            dy = _dy_f32(K, dy)                         # some consumer below reads the fp32 tensor
+        if not use16:
+            dy16 = None
         xa16 = ctx.x16 if use16 else None
         if ctx.needs_input_grad[0]:
             dxa = torch.empty(x.shape, dtype=torch.float32, device=x.device)
             fused = in_scale is not None and getattr(K, "supports_fused_norm_bwd", lambda: False)()
+            kw16 = dict(x16=dg16) if dg16 is not None else {}
             if fused:
                 # the InstanceNorm-backward sums come out of the data gradient's epilogue: one pass over (g, x) less
                 sums = K.new_stats(x.shape[0], spec.cin, x.device)
                 K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op,
-                       stats=sums, nb=(x, in_scale, in_shift, ctx.slope))
+                       stats=sums, nb=(x, in_scale, in_shift, ctx.slope), **kw16)
                 emits = getattr(K, "APPLY_EMITS", ())
                 want_xa, want_dx = use16 and "xa" in emits, ctx.up16 and "dx" in emits
                 if want_xa or want_dx:
                     # the apply pass has x, its statistics and dx in registers: it also writes this layer's weight-gradient operand
-                    # bf16(act(IN(x))) and the bf16 image of dx for the layer that produced x
+                    # bf16(act(IN(x))) and the bf16 image of dx for the layer that produced x -- and ONLY that image where the layer
+                    # that produced x reads nothing else (ctx.up16 == "only", a single-consumer graph)
+                    only16 = want_dx and ctx.up16 == "only" and _SINGLE_CONSUMER and to_sink
                     dx, dx16, xa16 = K.in_bwd_apply16(dxa, x, in_scale, in_shift, ctx.slope, sums, dx_add=dcarry,
-                                                      want_dx16=want_dx, want_xa16=want_xa)
+                                                      want_dx16=want_dx, want_xa16=want_xa, need_f32=not only16)
                     if dx16 is not None:
                         dx._cwf16 = dx16
+                        if only16:
+                            dx._cwf_f32_missing = True
                 else:
                     dx = K.in_bwd_apply(dxa, x, in_scale, in_shift, ctx.slope, sums, dx_add=dcarry)
             elif in_scale is not None:
@@ -259,9 +271,9 @@ class _ConvFn(torch.autograd.Function):
                     # tail's dL/dy, so the epilogue also accumulates the tail's InstanceNorm-backward sums
                     link.sums = K.new_stats(x.shape[0], spec.cin, x.device)
                     dx = K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op, residual=dcarry,
-                                stats=link.sums, nb=(link.g, link.scale, link.shift, link.slope))
+                                stats=link.sums, nb=(link.g, link.scale, link.shift, link.slope), **kw16)
                 else:
-                    dx = K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op, residual=dcarry)
+                    dx = K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op, residual=dcarry, **kw16)
         elif dcarry is not None:
             dx = dcarry
         if to_sink:
@@ -344,6 +356,24 @@ def fused_conv3(x, convs, spec):
     return y, (sc, sh)
 
 
+# A model may declare that every tensor it hands to conv() / norm_act_add() has ONE gradient consumer (ClsWiseFormer does, in its
+# forward).  Only then may a backward pass leave the fp32 gradient of such a tensor unwritten and hand on its bf16 image alone
+# (autograd would otherwise add the unwritten buffer to another consumer's gradient).
+_SINGLE_CONSUMER = False
+
+
+def set_single_consumer_graph(flag: bool):
+    global _SINGLE_CONSUMER
+    _SINGLE_CONSUMER = bool(flag)
+
+
+def _dy_f32(K, dy):
+    """the fp32 gradient, materialised from its bf16 image if the producer left the fp32 tensor unwritten (rare paths only)"""
+    if getattr(dy, "_cwf_f32_missing", False):
+        return dy._cwf16.float()
+    return dy
+
+
 class CarryLink:
     """Side channel for the gradient of a carried alias (conv(..., carry=True) hands its input on as a second output; a residual
     connection consumes it).  A conv that takes the alias as its `residual` appends dL/d(residual) -- which IS its incoming dy -- here
@@ -377,7 +407,10 @@ def conv(x, w, b, spec, in_norm=None, slope=1.0, residual=None, out_scale=None, 
     ok16 = getattr(backend(), "bf16_operands_ok", None)
     if ok16 is not None and residual is None and out_scale is None and torch.is_grad_enabled() and \
             ok16(spec.op, spec.cin, spec.cout, y.shape[1] * y.shape[2] * y.shape[3]):
-        y._cwf_want16 = True      # whoever computes dL/dy (an InstanceNorm-backward apply pass) adds its bf16 image (this layer's kernels take it)
+        # whoever computes dL/dy (an InstanceNorm-backward apply pass) adds its bf16 image: this layer's kernels take it -- both of
+        # them ("only") if its data gradient reads bf16 images too
+        okd = getattr(backend(), "bf16_dgrad_ok", None)
+        y._cwf_want16 = "only" if (okd is not None and okd(spec.op, spec.cin, spec.cout, y.shape[1] * y.shape[2] * y.shape[3])) else True
     st = (s1, s2) if want_stats else None
     return (y, st, xc) if carry else (y, st)
 
@@ -482,7 +515,7 @@ class _NormActAddFn(torch.autograd.Function):
         ctx.slope = slope
         ctx.has_res = residual is not None
         ctx.link = link
-        ctx.up16 = bool(getattr(x, "_cwf_want16", False))
+        ctx.up16 = getattr(x, "_cwf_want16", False)
         ctx.save_for_backward(x, scale, shift)
         if want16:
             y, y16 = backend().norm_act_add(x, scale, shift, slope, residual, want16=True)
@@ -498,8 +531,11 @@ class _NormActAddFn(torch.autograd.Function):
         if link is not None and link.sums is not None and not link.shared:
             sums, link.sums = link.sums, None        # from the consuming conv's data-gradient epilogue (this backward pass)
             if ctx.up16 and "dx" in getattr(K, "APPLY_EMITS", ()):
-                dx, dx16, _ = K.in_bwd_apply16(dy, x, scale, shift, ctx.slope, sums, want_dx16=True)
+                only16 = ctx.up16 == "only" and _SINGLE_CONSUMER and active_sink() is not None
+                dx, dx16, _ = K.in_bwd_apply16(dy, x, scale, shift, ctx.slope, sums, want_dx16=True, need_f32=not only16)
                 dx._cwf16 = dx16
+                if only16:
+                    dx._cwf_f32_missing = True
             else:
                 dx = K.in_bwd_apply(dy, x, scale, shift, ctx.slope, sums)
         else:

@@ -206,7 +206,7 @@ class HipBackend:
 
     # ------------------------------------------------------------------ K1
     def conv(self, op, x, wpk, bias, cout, in_scale=None, in_shift=None, slope=1.0, residual=None, out_scale=None,
-             stats=None, out=None, w_ref=None, out_channels_alloc=None, fwd_op=None, prec=None, nb=None, bias_ref=None):
+             stats=None, out=None, w_ref=None, out_channels_alloc=None, fwd_op=None, prec=None, nb=None, bias_ref=None, x16=None):
         """Returns the output buffer.  With out_channels_alloc > cout the buffer has zero-filled padding channels
         (2-channel heads live in 4-channel tensors so that every later kernel sees 16-byte voxel rows).
         w_ref / bias_ref (the original parameters; tuples for a fused layer) and fwd_op are not read here: the kernels take the
@@ -229,6 +229,18 @@ class HipBackend:
         if residual is not None:
             residual, r_ldc = cl(residual)
         mode = prec or ((_DGRAD_PRECISION or _PRECISION) if (fwd_op is not None) else _PRECISION)
+        if x16 is not None:
+            # the input as a bf16 image (bf16_dgrad_ok): conv16s with LDS-DMA loaders; x itself is not read
+            assert mode == "bf16" and in_scale is None and out_scale is None and x16.dtype == torch.bfloat16 and x16.is_contiguous()
+            assert tuple(x16.shape) == (n, di, hi, wi, 16) and cin == 16 and cout == 16
+            nbp = (0, 0, 0, 0, 1.0)
+            if nb is not None:
+                nb_x, nb_scale, nb_shift, nb_slope = nb
+                nb_x, nb_ldc = cl(nb_x)
+                nbp = (nb_x.data_ptr(), nb_ldc, nb_scale.data_ptr(), nb_shift.data_ptr(), float(nb_slope))
+            self._call("cwf_conv_mfma_bf16_in16", op, x16.data_ptr(), self.zero16(x.device).data_ptr(), wpk.data_ptr(), _p(bias),
+                       y.data_ptr(), y_ldc, _p(residual), r_ldc, _p(stats), *nbp, n, di, hi, wi, self._stream())
+            return y
         if mode == "fp32":
             self._call("cwf_conv_mfma", op, x.data_ptr(), x_ldc, wpk.data_ptr(), _p(bias), y.data_ptr(), y_ldc,
                        _p(in_scale), _p(in_shift), float(slope), _p(residual), r_ldc, _p(out_scale), _p(stats),
@@ -280,6 +292,13 @@ class HipBackend:
         if os.environ.get("CWF_NO_BF16_OPERANDS"):
             return False
         return op == pk.CONV3_S1 and cin == 16 and cout == 16 and nvox >= 32768 and (_WGRAD_PRECISION or _PRECISION) == "bf16"
+
+    def bf16_dgrad_ok(self, op, cin, cout, nvox):
+        """the data gradient of such a layer can read its incoming gradient as a bf16 image (conv(..., x16=))"""
+        import os
+        if os.environ.get("CWF_NO_BF16_OPERANDS") or os.environ.get("CWF_NO_BF16_DGRAD"):
+            return False
+        return op == pk.CONV3_S1 and cin == 16 and cout == 16 and nvox >= 32768 and (_DGRAD_PRECISION or _PRECISION) == "bf16"
 
     def zero16(self, device):
         z = getattr(self, "_zero16", None)

@@ -208,6 +208,8 @@ class ClsWiseFormer(nn.Module):
                              % (self.top_num, self.top_num * 2048, d, h, w))
         self.aux = {}
         self._cut_state = {}
+        # every conv output / block tail of this model has ONE gradient consumer: a backward pass may hand on a bf16 gradient image alone
+        CF.set_single_consumer_graph(True)
         backend().begin_step(x.device)
         self._packer.refresh()
         xc = x.to(torch.float32).permute(0, 2, 3, 4, 1).contiguous()  # NDHWC

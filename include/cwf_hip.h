@@ -169,6 +169,13 @@ int cwf_norm_act_add_ex(const float* x, int x_ldc, const float* scale, const flo
 /* y16 [N*V][C] bf16 = bf16(act(x*scale+shift))  (scale == NULL: bf16(x)) */
 int cwf_to_bf16(const float* x, int x_ldc, const float* scale, const float* shift, float slope, void* y16,
                 int N, int64_t V, int C, void* stream);
+/* cwf_conv_mfma_bf16_nb (single-bf16 operand products) for a 3x3x3 stride-1 16 -> 16 layer of >= 32768 voxels whose INPUT exists as a
+ * bf16 image x16 [N][D][H][W][16] -- the data gradient of EnBlock1 / EnBlock1_1 / DeBlock2 / DeBlock2_1 reading the bf16 image of dy that
+ * cwf_in_bwd_apply_ex wrote (the data half of aten::convolution_backward, Unet_skipconnection.py:36-57).  zero16: 16 zero bytes. */
+int cwf_conv_mfma_bf16_in16(int op, const void* x16, const void* zero16, const void* wpk16, const float* bias,
+                            float* y, int y_ldc, const float* residual, int r_ldc, double* stats,
+                            const float* nb_x, int nb_ldc, const float* nb_scale, const float* nb_shift, float nb_slope,
+                            int N, int D, int H, int W, void* stream);
 /* Weight / bias gradient slabs of a 3x3x3 stride-1 16 -> 16 conv (padding 1) from bf16 operand images (single-bf16 products, fp32
  * accumulate): xa16 = bf16(act(IN(x))) [N][D][H][W][16], dy16 [N][D][H][W][16], zero16 = 16 zero bytes (the padding source of the
  * LDS-DMA loaders).  Slab layout and reduction: cwf_wgrad_mfma_bf16(CWF_CONV3_S1, 16, 16) / cwf_wgrad_reduce.

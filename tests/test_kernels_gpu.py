@@ -152,6 +152,34 @@ def test_fused_norm_backward_sums(hip, op, cin, cout, size, n, prec):
     close(dx_fused, dx_two_pass.cpu(), rtol=2e-5, what="fused norm backward")
 
 
+@pytest.mark.parametrize("size,n", [((64, 64, 64), 2), ((34, 38, 50), 1)])
+def test_conv16s_reads_a_bf16_input_image(hip, size, n):
+    """Round 3: the full-resolution 16-channel data gradient with its input as a bf16 image (conv(..., x16=): LDS-DMA loaders, a
+    16-row ring): bit-equal to the fp32-input launch in single-bf16 mode (same operand values, same MFMA order), with the residual
+    and the fused InstanceNorm-backward sums; ragged tiles / borders included."""
+    from cwf import functional as CF
+    d, h, w_ = size
+    c = 16
+    dy = rnd(n, d, h, w_, c, seed=31).to(DEV)
+    x = rnd(n, d, h, w_, c, seed=32).to(DEV)
+    res = rnd(n, d, h, w_, c, seed=33).to(DEV)
+    sc = (rnd(n, c, seed=34).abs() + 0.5).to(DEV)
+    sh = rnd(n, c, seed=35).to(DEV)
+    w = rnd(c, c, 3, 3, 3, seed=36, scale=1.0 / math.sqrt(c * 27))
+    spec = _packed(CF.ConvSpec(pk.CONV3_S1, c, c), w, "bf16")
+    dy16 = hip.to_bf16(dy)
+    for kw in (dict(), dict(residual=res), dict(nb=(x, sc, sh, 0.01)), dict(residual=res, nb=(x, sc, sh, 0.0))):
+        outs = []
+        for img in (None, dy16):
+            st = hip.new_stats(n, c, DEV) if "nb" in kw else None
+            y = hip.conv(pk.CONV3_S1, dy, spec.wpk16_d, None, c, out=torch.empty((n, d, h, w_, c), device=DEV), prec="bf16",
+                         fwd_op=pk.CONV3_S1, stats=st, x16=img, **kw)
+            outs.append((y, st))
+        assert torch.equal(outs[0][0], outs[1][0]), sorted(kw)
+        if outs[0][1] is not None:
+            close(outs[1][1], outs[0][1].cpu(), rtol=1e-6, what="nb sums")          # (fp32 partial sums folded by f64 atomics)
+
+
 def _bf16_rne(t):
     """round-to-nearest-even bf16 of an fp32 tensor (what v_cvt_pk_bf16_f32 does)"""
     return t.to(torch.bfloat16)
