@@ -187,6 +187,12 @@ class _ConvFn(torch.autograd.Function):
         ok16 = getattr(K, "bf16_operands_ok", None)
         ctx.use16 = bool(ok16 is not None and ok16(spec.op, spec.cin, spec.cout, y.shape[1] * y.shape[2] * y.shape[3]))
         ctx.x16 = getattr(x, "_cwf16x", None) if (ctx.use16 and in_scale is None) else None     # bf16(x) from x's producer (a block tail)
+        if ctx.use16 and ctx.x16 is None and ctx.needs_input_grad[1] and getattr(K, "wgrad_async", False) and \
+                getattr(K, "xa16_in_forward", False):            # (wgrad_async: a Trainer step -- the gradient-sink path will run)
+            # the weight-gradient operand bf16(act(IN(x))) depends on forward data only: made NOW, on the weight-gradient side stream,
+            # which idles during the forward pass -- the backward pass then neither converts it nor waits for this layer's own
+            # InstanceNorm-backward apply pass (which matters for the last layers of backward: nothing is left to hide behind)
+            ctx.x16 = K.to_bf16_side(x, in_scale, in_shift, slope)
         ctx.up16 = getattr(x, "_cwf_want16", False)     # x's producer is such a layer: hand its gradient on with a bf16 image ("only": nothing else)
         ctx.save_for_backward(x, w, in_scale, in_shift, out_scale)
         # carry: x is handed on as a second output (an alias).  Whatever consumes that alias (a residual connection, a skip
@@ -405,12 +411,14 @@ def conv(x, w, b, spec, in_norm=None, slope=1.0, residual=None, out_scale=None, 
     if carry_link is not None and xc is not None:
         xc._cwf_carry = carry_link
     ok16 = getattr(backend(), "bf16_operands_ok", None)
-    if ok16 is not None and residual is None and out_scale is None and torch.is_grad_enabled() and \
+    if ok16 is not None and out_scale is None and torch.is_grad_enabled() and \
             ok16(spec.op, spec.cin, spec.cout, y.shape[1] * y.shape[2] * y.shape[3]):
         # whoever computes dL/dy (an InstanceNorm-backward apply pass) adds its bf16 image: this layer's kernels take it -- both of
         # them ("only") if its data gradient reads bf16 images too
         okd = getattr(backend(), "bf16_dgrad_ok", None)
-        y._cwf_want16 = "only" if (okd is not None and okd(spec.op, spec.cin, spec.cout, y.shape[1] * y.shape[2] * y.shape[3])) else True
+        # (with a residual the fp32 gradient is needed as well: it is the residual's gradient)
+        y._cwf_want16 = "only" if (residual is None and okd is not None and
+                                   okd(spec.op, spec.cin, spec.cout, y.shape[1] * y.shape[2] * y.shape[3])) else True
     st = (s1, s2) if want_stats else None
     return (y, st, xc) if carry else (y, st)
 

@@ -285,7 +285,7 @@ class HipBackend:
     # (CWF_APPLY_EMITS="xa,dx", "" = none): each costs the main stream 2 B per element; without it a conversion pass in front of the
     # weight gradient costs the side stream 6 B per element.  Measured (plan mode, one box, volumes/s): none 102.7, dx 104.2, xa,dx 106.2.
     import os as _os
-    APPLY_EMITS = tuple(t for t in _os.environ.get("CWF_APPLY_EMITS", "xa,dx").split(",") if t)
+    APPLY_EMITS = tuple(t for t in _os.environ.get("CWF_APPLY_EMITS", "dx" if _os.environ.get("CWF_XA16_FWD", "0") != "0" else "xa,dx").split(",") if t)
 
     def bf16_operands_ok(self, op, cin, cout, nvox):
         import os
@@ -333,6 +333,25 @@ class HipBackend:
         n, d, h, w, c = x.shape
         y = torch.empty((n, d, h, w, c), dtype=torch.bfloat16, device=x.device)
         self._call("cwf_to_bf16", x.data_ptr(), x_ldc, _p(scale), _p(shift), float(slope), y.data_ptr(), n, d * h * w, c, self._stream())
+        return y
+
+    # CWF_XA16_FWD=1: bf16(act(IN(x))) of the eligible layers during the FORWARD pass, on the weight-gradient side stream (idle then);
+    # default: the apply pass / a conversion in front of the weight gradient makes it during backward
+    import os as _os2
+    # (measured: 105.9 volumes/s against 108.5 with the apply pass writing it -- the conversions slow the forward's own kernels; off)
+    xa16_in_forward = _os2.environ.get("CWF_XA16_FWD", "0") != "0"
+
+    def to_bf16_side(self, x, scale, shift, slope):
+        if not self.wgrad_async:
+            return self.to_bf16(x, scale, shift, slope)
+        side = self.wgrad_stream(x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(side):
+            y = self.to_bf16(x, scale, shift, slope)
+        for t in (x, scale, shift):
+            if t is not None:
+                t.record_stream(side)
+        y.record_stream(torch.cuda.current_stream(x.device))      # (consumed on the side stream; freed by whoever drops the last reference)
         return y
 
     def conv_grouped(self, x_all, cin, wpks, biases, cout, y_all, x_goff, y_goff, w_refs=None, fwd_op=None, prec=None):

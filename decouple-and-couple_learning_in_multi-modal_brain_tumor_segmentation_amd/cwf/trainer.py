@@ -140,11 +140,11 @@ class Trainer:
         self.opt._ensure()
         sink = self.opt.sink
         sink.begin()
+        K = kernels_backend()
+        K.wgrad_async = self.wgrad_async       # (from the forward pass on: it prepares weight-gradient operands on the side stream)
         outputs = self.model(x, None)
         loss, parts = total_loss(outputs, target, edge)
         self.opt.zero_grad(set_to_none=True)
-        K = kernels_backend()
-        K.wgrad_async = self.wgrad_async
         if hasattr(K, "flush_every_default"):
             K.flush_every = (1 << 30) if self.use_graph else K.flush_every_default   # (graph mode: one reduce per phase, in warm-up too)
         if hasattr(K, "wgrad_release"):
