@@ -19,9 +19,26 @@ packer = CF.WeightPacker(); packer.add(spec, w); packer.refresh()
 sc = torch.ones((n, c), device=dev); sh = torch.zeros((n, c), device=dev)
 y = torch.empty_like(x); dy = torch.randn_like(x)
 stats = K.new_stats(n, c, dev)
+# round 3: the bf16-image kernels (what: wgradd = wgrad16d_kernel, dgrad16 = conv16s IN16 with residual + norm-backward sums as in the
+# step, dgrad16p = IN16 plain, apply16 = in_bwd_apply writing only the two bf16 images).  Run with prec "bf16".
+if what in ("wgradd", "dgrad16", "dgrad16p", "apply16"):
+    kernels.set_precision("bf16x3", wgrad="bf16", dgrad="bf16")
+    packer.refresh()
+    x16 = K.to_bf16(x, sc, sh, 0.0); dy16 = K.to_bf16(dy); res = torch.randn_like(x)
+    dw = torch.zeros(w.numel(), device=dev); db = torch.zeros(c, device=dev)
+    sums = K.new_stats(n, c, dev)
 def run():
     if what == "conv":
         K.conv(pk.CONV3_S1, x, spec.packed(False), b, c, sc, sh, 0.0, None, None, stats, out=y)
+    elif what == "wgradd":
+        K._wgrad_to_impl("micro", pk.CONV3_S1, x, sc, sh, 0.0, dy, c, spec.inv_map, dw, db, None, x16, dy16)
+        K._wg_pending.clear()
+    elif what == "dgrad16":
+        K.conv(pk.CONV3_S1, dy, spec.packed(True), None, c, out=y, fwd_op=pk.CONV3_S1, prec="bf16", x16=dy16, residual=res, stats=sums, nb=(x, sc, sh, 0.0))
+    elif what == "dgrad16p":
+        K.conv(pk.CONV3_S1, dy, spec.packed(True), None, c, out=y, fwd_op=pk.CONV3_S1, prec="bf16", x16=dy16)
+    elif what == "apply16":
+        K.in_bwd_apply16(dy, x, sc, sh, 0.0, sums, want_dx16=True, want_xa16=True, need_f32=False)
     else:
         K.wgrad(pk.CONV3_S1, x, sc, sh, 0.0, dy, c, spec.inv_map, True, w.numel())
 for _ in range(3): run()

@@ -1,11 +1,8 @@
 set -e
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests/test_model_gpu.py -x -q -m gpu 2>&1 | tail -3
+timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "bf16_input_image or fused_norm_backward or conv_family" 2>&1 | tail -3
 run() { tag=$1; shift; env "$@" python bench.py --steps 30 --warmup 6 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$tag', j['value'], j['ms_per_step'], j['config'].get('plan'))"; }
 run base A=1
-run xa_bwd CWF_XA16_FWD=0
-run defer0 CWF_DEFER_WGRAD=0
-run defer2 CWF_DEFER_WGRAD=2
-run wgs160 CWF_SIDE_WGS=160
 run off CWF_NO_BF16_OPERANDS=1
 run base2 A=1
+python tools/conv16_micro.py bf16 10 conv 2>&1 | tail -3
