@@ -54,14 +54,26 @@ for (op, cin, cout, ext, normed, wstats), mods in sorted(seen.items(), key=lambd
     dy = torch.randn_like(y); dx = torch.empty_like(xin)
     if y.shape[-1] != cout:
         dy[..., cout:] = 0
-    d = timeit(lambda: K.conv(pk.dgrad_op(op), dy, spec.packed(True), None, cin, out=dx, w_ref=w, fwd_op=op))
     dyv = dy[..., :cout]
-    wg = timeit(lambda: K.wgrad(op, xin, sc if normed else None, sh if normed else None, 0.01, dyv, cout, spec.inv_map, spec.has_bias_map, w.numel()))
+    img = K.bf16_operands_ok(op, cin, cout, y.shape[1] * y.shape[2] * y.shape[3])
+    if img:
+        # round 3: these layers run on bf16 operand images in the step (written by the InstanceNorm-backward apply passes): the
+        # data gradient reads dy16 (conv16s IN16), the weight gradient xa16 and dy16 (wgrad16d); marked '*'
+        dy16 = K.to_bf16(dyv); x16 = K.to_bf16(xin, sc if normed else None, sh if normed else None, 0.01)
+        dwb = torch.zeros(w.numel(), device=dev); dbb = torch.zeros(cout, device=dev)
+        d = timeit(lambda: K.conv(pk.dgrad_op(op), dy, spec.packed(True), None, cin, out=dx, w_ref=w, fwd_op=op, x16=dy16))
+        def wg_img():
+            K._wgrad_to_impl(("lt", cin, cout, ext), op, xin, None, None, 1.0, dyv, cout, spec.inv_map, dwb, dbb, None, x16, dy16)
+            K.wgrad_flush(dev)
+        wg = timeit(wg_img)
+    else:
+        d = timeit(lambda: K.conv(pk.dgrad_op(op), dy, spec.packed(True), None, cin, out=dx, w_ref=w, fwd_op=op))
+        wg = timeit(lambda: K.wgrad(op, xin, sc if normed else None, sh if normed else None, 0.01, dyv, cout, spec.inv_map, spec.has_bias_map, w.numel()))
     vin, vout = xin.numel() // cin, y.numel() // y.shape[-1]
     byts = 4.0 * (xin.numel() + vout * cout)
     flops = 2.0 * taps[op] * cin * cout * (vout if op != pk.CONVT2 else vout)
     floor = byts / 8e12 * 1e6
     mf = 3 * flops / 2.5e15 * 1e6
-    print("%-8s %4d %4d %-14s %3d | %8.1f %8.1f %6.1f %6.1f | %8.1f %6.1f | %8.1f %6.1f" % (names[op], cin, cout, "x".join(map(str, ext)), len(mods), f, floor, 100 * floor / f, 100 * mf / f, d, 100 * floor / d, wg, 100 * floor / wg), flush=True)
+    print("%-8s %4d %4d %-14s %3d | %8.1f %8.1f %6.1f %6.1f | %8.1f %6.1f | %8.1f %6.1f%s" % (names[op], cin, cout, "x".join(map(str, ext)), len(mods), f, floor, 100 * floor / f, 100 * mf / f, d, 100 * floor / d, wg, 100 * floor / wg, " *" if img else ""), flush=True)
     tot_f += f * len(mods); tot_d += d * len(mods); tot_w += wg * len(mods)
 print("sum over layers: forward %.2f ms, data gradient %.2f ms, weight gradient (slabs + reduce) %.2f ms" % (tot_f / 1e3, tot_d / 1e3, tot_w / 1e3))
