@@ -1137,6 +1137,203 @@ __global__ __launch_bounds__(256 + 64 * WS1_LW) void wgrad_s1_kernel(const WgArg
 }
 
 // ---------------------------------------------------------------------------------------------------
+// wgrad_s1d: wgrad_s1 (32-channel output groups) on bf16 OPERAND IMAGES filled by LDS-DMA -- the wgrad16d recipe for the 32 / 64 / 128-
+// channel 3x3x3 stride-1 layers: xa16 [N][D][H][W][Cin] and dy16 [N][D][H][W][Cout] bf16 (written by the InstanceNorm-backward apply
+// passes / block tails, or by cwf_to_bf16), eight loader waves issue nothing but global_load_lds_dwordx4 pieces -- 23 for the x image of
+// the workgroup's 16-channel chunk (wgrad16d's), 16 for the dy image (one M-tile row of 16 voxels x 32 channels IS one 1-KiB piece;
+// the 32-byte skew of odd rows moves the piece's base) -- into a four-buffer ring, three tiles in flight.  MFMA waves, slab layout
+// and (chunk, group) blocking: wgrad_s1_kernel<2>.  (wgrad_s1 moves 3.3-3.5x its algorithmic bytes from L2 as fp32; this form
+// moves the same halo-amplified voxels at half the bytes, without conversion work and with three tiles of latency cover.)
+// ---------------------------------------------------------------------------------------------------
+#define WS1D_XP 23
+#define WS1D_DP 16
+#define WS1D_XIB (WS1D_XP * 1024)
+#define WS1D_DIB (16 * 1024 + 8 * 32)                   // 16 rows + the skew of the odd rows
+#define WS1D_BUFB (WS1D_XIB + WS1D_DIB)                 // 40,192 B per buffer
+#define WS1D_NBUF 4
+struct Ws1dArgs {
+  const uint4* xa; const uint4* dy; const uint4* zero; float* partial;
+  int N, D, H, W, Cin, Cout, tiles_d, tiles_h, tiles_w, total_tiles, tiles_per_split, ngroups;
+  int64_t slab_floats;
+};
+
+__global__ __launch_bounds__(256 + 64 * WS1_LW) void wgrad_s1d_kernel(const Ws1dArgs a) {
+  constexpr int NTW = 2, CG = 2, CGW = 32, XW = 20, DP = 16, DSK = 16;
+  extern __shared__ float4 lds4[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x;
+  const int chunk = blockIdx.y / a.ngroups, grp = blockIdx.y % a.ngroups;
+  const int tiles_sp = a.tiles_d * a.tiles_h * a.tiles_w;
+  const int t_begin = split * a.tiles_per_split;
+  const int t_end = min(a.total_tiles, t_begin + a.tiles_per_split);
+  const int niter = max(t_end - t_begin, 0);
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds4;
+
+  if (wave < 4) {
+    // =============================================================== MFMA waves (wgrad_s1_kernel<2>, four buffers)
+    const int kq = lane >> 4, bq = (lane & 15) >> 2, bp = lane & 3;
+    f32x4 acc[7][NTW];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
+    const bool bias_wave = wave == 3;
+    const unsigned lane_x = lds_base + (((kq & 1) * XW + (kq >> 1) * 8 + bq) * 16 + bp * 4) * 2;
+    unsigned xa0[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int t = wave + 4 * i;
+      xa0[i] = lane_x + (t < 27 ? (((t / 9) * 6 + (t / 3) % 3) * XW + t % 3) * 32 : 0);
+    }
+    const unsigned da0 = lds_base + WS1D_XIB + (((kq & 1) * DP + (kq >> 1) * 8 + bq) * CGW + (kq & 1) * DSK + bp * 4) * 2;
+    auto trf = [&](unsigned addr, unsigned second) __attribute__((always_inline)) {
+      const s16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)addr);
+      const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(addr + second));
+      const s16x8 w = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+      return __builtin_bit_cast(bf16x8, w);
+    };
+    for (int it = 0; it < niter; ++it) {
+      asm volatile("s_barrier" ::: "memory");              // buffer it & 3 has landed
+      const unsigned bo = (unsigned)(it & 3) * WS1D_BUFB;
+      unsigned xa[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) xa[i] = xa0[i] + bo;
+      const unsigned da = da0 + bo;
+      constexpr int DEPTH = CWF_WS1_DEPTH;
+      bf16x8 ah[DEPTH + 1], bh[2][NTW];
+      auto issue = [&](int f) __attribute__((always_inline)) {
+        const int ks = f / 7, i = f % 7;
+        if (i == 0) {
+          const unsigned od_ = (2 * ks * DP * CGW + ks * DSK) * 2;
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) bh[ks & 1][j] = trf(da + od_ + j * 32, 4 * CGW * 2);
+        }
+        const unsigned ox = (((ks >> 1) * 6 + ((2 * ks) & 3)) * XW) * 32;
+        ah[f % (DEPTH + 1)] = trf(xa[i] + ox, 4 * 32);
+      };
+#pragma unroll
+      for (int f = 0; f < DEPTH; ++f) issue(f);
+#pragma unroll
+      for (int f = 0; f < 56; ++f) {
+        if (f + DEPTH < 56) issue(f + DEPTH);
+        __builtin_amdgcn_sched_barrier(0);
+        const int ks = f / 7, i = f % 7;
+        bf16x8 ahf = ah[f % (DEPTH + 1)];
+        if (i == 6) ahf = bias_wave ? ones : ahf;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahf, bh[ks & 1][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    float4* out = reinterpret_cast<float4*>(a.partial + (int64_t)split * a.slab_floats);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int t = wave + 4 * i;
+      if (t > 27) continue;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int64_t blk = (((int64_t)chunk * a.ngroups + grp) * 28 + t) * CG + j;
+        out[blk * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    }
+  } else {
+    // =============================================================== loader waves: DMA only
+    const int lw = wave - 4;                               // pieces lw, lw + 8, ... of the 39
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef __attribute__((address_space(1))) const void* glb_vp;
+    const int gx = a.Cin >> 3, gd = a.Cout >> 3;           // 16-byte granules per voxel
+    auto run = [&](auto NI_) __attribute__((always_inline)) {
+      constexpr int NI = decltype(NI_)::value;
+      int off[NI]; unsigned crd[NI];
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int s = lw + WS1_LW * k;
+        if (s < WS1D_XP) {
+          const int gi = 64 * s + lane;
+          const int row = gi / 40, gr = gi % 40, w = gr >> 1, half = gr & 1;
+          const int c0 = row / 6, c1 = row % 6;
+          off[k] = ((c0 * a.H + c1) * a.W + w) * gx + chunk * 2 + half;
+          crd[k] = (unsigned)c0 | ((unsigned)c1 << 3) | ((unsigned)w << 6) | ((row < 36 && gr < 36) ? 1u << 11 : 0u);
+        } else {
+          const int m = s - WS1D_XP, w = lane >> 2, q = lane & 3;
+          off[k] = (((m >> 2) * a.H + (m & 3)) * a.W + w) * gd + grp * 4 + q;
+          crd[k] = (unsigned)(m >> 2) | ((unsigned)(m & 3) << 3) | ((unsigned)w << 6) | (1u << 11);
+        }
+      }
+      auto issue = [&](int it) __attribute__((always_inline)) {
+        const int tile = t_begin + it;
+        const int n = tile / tiles_sp; int rem = tile - n * tiles_sp;
+        const int tile_w = rem % a.tiles_w; rem /= a.tiles_w;
+        const int tile_h = rem % a.tiles_h; const int tile_d = rem / a.tiles_h;
+        const int od0 = tile_d * 4, oh0 = tile_h * 4, ow0 = tile_w * 16;
+        const int64_t vd = (((int64_t)n * a.D + od0) * a.H + oh0) * a.W + ow0;
+        const int64_t vx = vd - ((int64_t)a.H + 1) * a.W - 1;
+        const unsigned lbuf = lds_base + (unsigned)(it & 3) * WS1D_BUFB;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+          const int s = lw + WS1_LW * k;                   // (wave-uniform)
+          const bool isd = s >= WS1D_XP;
+          const int c0 = (int)(crd[k] & 7u), c1 = (int)((crd[k] >> 3) & 7u), w = (int)((crd[k] >> 6) & 31u);
+          const int gdd = (isd ? od0 : od0 - 1) + c0, gh = (isd ? oh0 : oh0 - 1) + c1, gw = (isd ? ow0 : ow0 - 1) + w;
+          const bool ok = (crd[k] >> 11) != 0u && (unsigned)gdd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
+          const uint4* src = (isd ? a.dy + vd * gd : a.xa + vx * gx) + off[k];
+          src = ok ? src : a.zero;
+          const int m = s - WS1D_XP;
+          const unsigned dst = isd ? (unsigned)(WS1D_XIB + m * 1024 + ((m + 1) >> 1) * 32) : (unsigned)s * 1024u;
+          __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(uintptr_t)(lbuf + dst), 16, 0, 0);
+        }
+      };
+      if (niter > 0) issue(0);
+      if (niter > 1) issue(1);
+      if (niter > 2) issue(2);
+      for (int it = 0; it < niter; ++it) {
+        if (it + 2 < niter) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (it + 3 < niter) issue(it + 3);
+      }
+    };
+    constexpr int NP = WS1D_XP + WS1D_DP;
+    if (lw < NP % WS1_LW) run(std::integral_constant<int, NP / WS1_LW + 1>{});
+    else run(std::integral_constant<int, NP / WS1_LW>{});
+  }
+}
+
+extern "C" int64_t cwf_wgrad_slab_floats(int op, int Cin, int Cout);
+extern "C" int cwf_wgrad_s1_bf16(const void* xa16, const void* dy16, const void* zero16, float* partial,
+                                 int N, int D, int H, int W, int Cin, int Cout, int* nsplit_used, void* stream) {
+  if (!xa16 || !dy16 || !zero16 || !partial || N <= 0 || D <= 0 || H <= 0 || W <= 0) return CWF_E_BADARG;
+  if (((uintptr_t)xa16 & 15) || ((uintptr_t)dy16 & 15) || ((uintptr_t)zero16 & 15) || ((uintptr_t)partial & 15)) return CWF_E_ALIGN;
+  if (Cin < 16 || (Cin & 15) || Cout < 32 || (Cout & 31)) return CWF_E_BADARG;
+  if ((int64_t)N * D * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 33)) return CWF_E_TOOLARGE;
+  Ws1dArgs a;
+  a.xa = (const uint4*)xa16; a.dy = (const uint4*)dy16; a.zero = (const uint4*)zero16; a.partial = partial;
+  a.N = N; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.tiles_d = cdiv(D, 4); a.tiles_h = cdiv(H, 4); a.tiles_w = cdiv(W, 16);
+  a.total_tiles = N * a.tiles_d * a.tiles_h * a.tiles_w;
+  const int nchunks = Cin / 16;
+  a.ngroups = Cout / 32;
+  const int nblk = nchunks * a.ngroups;
+  a.slab_floats = (int64_t)nblk * 28 * 2 * 256;
+  if (a.slab_floats != cwf_wgrad_slab_floats(CWF_CONV3_S1, Cin, Cout)) return CWF_E_BADARG;
+  int want = side_wgs() / nblk; if (want < 1) want = 1; if (want > a.total_tiles) want = a.total_tiles;
+  a.tiles_per_split = cdiv(a.total_tiles, want);
+  const int splits = cdiv(a.total_tiles, a.tiles_per_split);
+  if (splits > cwf_wgrad_nsplit(CWF_CONV3_S1, N, D, H, W, Cin, Cout)) return CWF_E_BADARG;     // (the caller's slab buffer is sized by it)
+  const size_t lds = (size_t)WS1D_NBUF * WS1D_BUFB;
+  CWF_MAX_LDS_ONCE((&wgrad_s1d_kernel));
+  hipLaunchKernelGGL(wgrad_s1d_kernel, dim3(splits, nblk), dim3(256 + 64 * WS1_LW), lds, cwf_stream(stream), a);
+  CWF_LAUNCH_CHECK();
+  if (nsplit_used) *nsplit_used = splits;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // pw_wgrad: weight gradients of the pointwise family (1x1x1 convs; ConvTranspose k = 2, s = 2), the counterpart of pw_conv_kernel
 // (conv_bf16.hip).  dW[ci][co] = sum_vox xa[vox][ci] * dy[vox][co] is a skinny product over a pure stream -- x and dy are each read
 // once, ~0.5 FLOP per byte -- and the generic 1-tap path above (stage a 256-voxel tile in LDS, barrier, transposed reads, barrier;

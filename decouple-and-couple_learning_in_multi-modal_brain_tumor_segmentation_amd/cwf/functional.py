@@ -556,8 +556,8 @@ def norm_act_add(x, stats, slope, residual=None, emit16=False):
     of that conv's weight gradient (HipBackend.bf16_operands_ok)."""
     link = NaaLink(x, stats[0], stats[1], float(slope)) if torch.is_grad_enabled() else None
     ok16 = getattr(backend(), "bf16_operands_ok", None)
-    want16 = bool(emit16 and torch.is_grad_enabled() and ok16 is not None and "xa" in getattr(backend(), "APPLY_EMITS", ()) and x.shape[-1] == 16 and
-                  ok16(pk.CONV3_S1, 16, 16, x.shape[1] * x.shape[2] * x.shape[3]))
+    want16 = bool(emit16 and torch.is_grad_enabled() and ok16 is not None and "xa" in getattr(backend(), "APPLY_EMITS", ()) and
+                  ok16(pk.CONV3_S1, x.shape[-1], x.shape[-1], x.shape[1] * x.shape[2] * x.shape[3]))
     y, y16 = _NormActAddFn.apply(x, stats[0], stats[1], float(slope), residual, link, want16)
     if link is not None:
         y._cwf_link = link                           # picked up by the conv that takes y as its (un-normalised) input

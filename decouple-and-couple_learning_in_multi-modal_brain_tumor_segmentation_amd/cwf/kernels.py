@@ -291,7 +291,13 @@ class HipBackend:
         import os
         if os.environ.get("CWF_NO_BF16_OPERANDS"):
             return False
-        return op == pk.CONV3_S1 and cin == 16 and cout == 16 and nvox >= 32768 and (_WGRAD_PRECISION or _PRECISION) == "bf16"
+        if op != pk.CONV3_S1 or (_WGRAD_PRECISION or _PRECISION) != "bf16":
+            return 0
+        if cin == 16 and cout == 16 and nvox >= 32768:
+            return 16                                      # wgrad16d_kernel
+        if cin >= 32 and cin % 16 == 0 and cout % 32 == 0 and not os.environ.get("CWF_NO_BF16_S1D"):
+            return 32                                      # wgrad_s1d_kernel (32-channel output groups)
+        return 0
 
     def bf16_dgrad_ok(self, op, cin, cout, nvox):
         """the data gradient of such a layer can read its incoming gradient as a bf16 image (conv(..., x16=))"""
@@ -467,7 +473,7 @@ class HipBackend:
         _, do, ho, wo, _ = dy.shape
         # eligible layers always take the bf16-image kernel; an image nobody handed over is made here, i.e. on the stream this launch
         # runs on (normally the side stream, which has slack: the main stream's kernels are the step's critical path)
-        use16 = prec is None and self.bf16_operands_ok(op, cin, cout, do * ho * wo)
+        use16 = self.bf16_operands_ok(op, cin, cout, do * ho * wo) if prec is None else 0
         nsplit = self.lib.cwf_wgrad_nsplit(op, n, do, ho, wo, cin, cout)
         slab = self.lib.cwf_wgrad_slab_floats(op, cin, cout)
         if nsplit <= 0 or slab <= 0 or slab != inv_map.numel():
@@ -484,10 +490,14 @@ class HipBackend:
             if dy16 is None:
                 dy16 = self.to_bf16(dy)
             assert x16.dtype == torch.bfloat16 and dy16.dtype == torch.bfloat16 and x16.is_contiguous() and dy16.is_contiguous()
-            assert tuple(x16.shape) == (n, di, hi, wi, 16) and tuple(dy16.shape) == (n, do, ho, wo, 16)
+            assert tuple(x16.shape) == (n, di, hi, wi, cin) and tuple(dy16.shape) == (n, do, ho, wo, cout)
             used = ctypes.c_int(0)
-            self._call("cwf_wgrad16_bf16", x16.data_ptr(), dy16.data_ptr(), self.zero16(x.device).data_ptr(), part.data_ptr(),
-                       n, di, hi, wi, ctypes.addressof(used), self._stream())
+            if use16 == 16:
+                self._call("cwf_wgrad16_bf16", x16.data_ptr(), dy16.data_ptr(), self.zero16(x.device).data_ptr(), part.data_ptr(),
+                           n, di, hi, wi, ctypes.addressof(used), self._stream())
+            else:
+                self._call("cwf_wgrad_s1_bf16", x16.data_ptr(), dy16.data_ptr(), self.zero16(x.device).data_ptr(), part.data_ptr(),
+                           n, di, hi, wi, cin, cout, ctypes.addressof(used), self._stream())
             nsplit = used.value
         elif mode == "fp32":
             self._call("cwf_wgrad_mfma", op, x.data_ptr(), x_ldc, _p(in_scale), _p(in_shift), float(slope),

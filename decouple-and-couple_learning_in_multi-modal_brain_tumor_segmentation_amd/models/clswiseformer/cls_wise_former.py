@@ -274,9 +274,10 @@ class Decoder(nn.Module):
 
     def forward(self, x1_1, x2_1, x3_1, x4_1, x, aux=None):
         x8, _ = self.down_channel(x)
-        x8 = self.Enblock8_2(self.Enblock8_1(x8))
-        y4 = self.DeBlock4_1(self.DeBlock4(self.DeUp4(x8, x3_1)))
-        y3 = self.DeBlock3_1(self.DeBlock3(self.DeUp3(y4, x2_1)))
+        # emit16: the next block's conv1 takes this block's output without a prologue (bf16 image for its weight gradient)
+        x8 = self.Enblock8_2(self.Enblock8_1(x8, emit16=True))
+        y4 = self.DeBlock4_1(self.DeBlock4(self.DeUp4(x8, x3_1), emit16=True))
+        y3 = self.DeBlock3_1(self.DeBlock3(self.DeUp3(y4, x2_1), emit16=True))
         y2 = self.DeBlock2_1(self.DeBlock2(self.DeUp2(y3, x1_1), emit16=True))
         logits, _ = self.endconv(y2)
         if aux is not None:

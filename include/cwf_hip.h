@@ -184,6 +184,12 @@ int cwf_conv_mfma_bf16_in16(int op, const void* x16, const void* zero16, const v
 int cwf_wgrad16_bf16(const void* xa16, const void* dy16, const void* zero16, float* partial,
                      int N, int D, int H, int W, int* nsplit_used, void* stream);
 
+/* The same for the 3x3x3 stride-1 layers with Cin a multiple of 16 (>= 32) and Cout a multiple of 32 (EnBlock2/3/4, DeBlock3/4, Enblock8,
+ * decouplers; Unet_skipconnection.py:36-57, cls_wise_former.py:691-754): xa16 [N][D][H][W][Cin], dy16 [N][D][H][W][Cout] bf16.
+ * Slab layout and reduction: cwf_wgrad_mfma_bf16(CWF_CONV3_S1, Cin, Cout) / cwf_wgrad_reduce. */
+int cwf_wgrad_s1_bf16(const void* xa16, const void* dy16, const void* zero16, float* partial,
+                      int N, int D, int H, int W, int Cin, int Cout, int* nsplit_used, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K6/K7  token path: LayerNorm, Linear (strided batched MFMA GEMM), softmax rows, GELU
  *        ResidualNorm.py:4-47, SelfAttention.py:74-102

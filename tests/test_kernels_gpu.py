@@ -180,6 +180,41 @@ def test_conv16s_reads_a_bf16_input_image(hip, size, n):
             close(outs[1][1], outs[0][1].cpu(), rtol=1e-6, what="nb sums")          # (fp32 partial sums folded by f64 atomics)
 
 
+@pytest.mark.parametrize("cin,cout,size,n", [(32, 32, (16, 16, 32), 2), (64, 64, (8, 12, 16), 1), (128, 256, (6, 6, 10), 2), (96, 96, (8, 8, 16), 1)])
+def test_dma_weight_gradient_32_channel_groups(hip, cin, cout, size, n):
+    """cwf_wgrad_s1_bf16 (wgrad_s1d_kernel: bf16 images by LDS-DMA, 16-channel chunks x 32-channel groups) against the fp32-tensor
+    kernel (same single-bf16 operands: summation order only) and the oracle; ragged tiles included."""
+    from cwf import functional as CF, kernels
+    import os
+    d, h, w_ = size
+    x = rnd(n, d, h, w_, cin, seed=41); g = rnd(n, d, h, w_, cout, seed=42)
+    sc = rnd(n, cin, seed=43).abs() + 0.5; sh = rnd(n, cin, seed=44)
+    xd, gd, scd, shd = x.to(DEV), g.to(DEV), sc.to(DEV), sh.to(DEV)
+    spec = CF.ConvSpec(pk.CONV3_S1, cin, cout).to(torch.device(DEV))
+    wn = cout * cin * 27
+    kernels.set_precision("bf16x3", wgrad="bf16", dgrad="bf16")
+    try:
+        assert hip.bf16_operands_ok(pk.CONV3_S1, cin, cout, d * h * w_) == 32
+        dw_a = torch.zeros(wn, device=DEV); db_a = torch.zeros(cout, device=DEV)
+        dw_b = torch.zeros(wn, device=DEV); db_b = torch.zeros(cout, device=DEV)
+        os.environ["CWF_NO_BF16_OPERANDS"] = "1"
+        try:
+            hip.wgrad_to(("s1a", cin, cout), pk.CONV3_S1, xd, scd, shd, 0.01, gd, cout, spec.inv_map, dw_a, db_a)
+            hip.wgrad_flush(torch.device(DEV))
+        finally:
+            del os.environ["CWF_NO_BF16_OPERANDS"]
+        hip.wgrad_to(("s1b", cin, cout), pk.CONV3_S1, xd, scd, shd, 0.01, gd, cout, spec.inv_map, dw_b, db_b)
+        hip.wgrad_flush(torch.device(DEV))
+    finally:
+        kernels.set_precision("fp32")
+    torch.cuda.synchronize()
+    close(dw_b, dw_a.cpu(), rtol=2e-5, what="dma wgrad vs fp32-tensor wgrad")
+    close(db_b, db_a.cpu(), rtol=2e-5, what="dma bgrad")
+    gw_ref, gb_ref = E.wgrad(pk.CONV3_S1, x, sc, sh, 0.01, g, cout, None, True, wn, w_ref_shape=(cout, cin, 3, 3, 3))
+    close(dw_b, gw_ref, rtol=PREC_TOL["bf16"], what="dma wgrad vs oracle")
+    close(db_b, gb_ref, rtol=PREC_TOL["bf16"], what="dma bgrad vs oracle")
+
+
 def _bf16_rne(t):
     """round-to-nearest-even bf16 of an fp32 tensor (what v_cvt_pk_bf16_f32 does)"""
     return t.to(torch.bfloat16)
@@ -225,7 +260,7 @@ def test_bf16_operand_images_and_dma_weight_gradient(hip, size, n):
     wn = c * c * 27
     kernels.set_precision("bf16x3", wgrad="bf16", dgrad="bf16")
     try:
-        assert hip.bf16_operands_ok(pk.CONV3_S1, c, c, d * h * w_) == (d * h * w_ >= 32768)
+        assert bool(hip.bf16_operands_ok(pk.CONV3_S1, c, c, d * h * w_)) == (d * h * w_ >= 32768)
         dw_a = torch.zeros(wn, device=DEV); db_a = torch.zeros(c, device=DEV)
         dw_b = torch.zeros(wn, device=DEV); db_b = torch.zeros(c, device=DEV)
         dw_c = torch.zeros(wn, device=DEV); db_c = torch.zeros(c, device=DEV)
