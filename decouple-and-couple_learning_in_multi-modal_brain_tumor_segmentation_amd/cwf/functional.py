@@ -410,6 +410,8 @@ def conv(x, w, b, spec, in_norm=None, slope=1.0, residual=None, out_scale=None, 
     y, s1, s2, xc = _ConvFn.apply(x, w, b, spec, sc, sh, float(slope), residual, out_scale, want_stats, carry, link, out, res_link, carry_link)
     if carry_link is not None and xc is not None:
         xc._cwf_carry = carry_link
+    if xc is not None and getattr(x, "_cwf_catbuf", None) is not None:
+        xc._cwf_catbuf = x._cwf_catbuf                   # the carried alias of a skip tensor still names its concatenation buffer
     ok16 = getattr(backend(), "bf16_operands_ok", None)
     if ok16 is not None and out_scale is None and torch.is_grad_enabled() and \
             ok16(spec.op, spec.cin, spec.cout, y.shape[1] * y.shape[2] * y.shape[3]):
@@ -602,12 +604,47 @@ class _CatIntoFn(torch.autograd.Function):
         return d[..., :ctx.ca], d[..., ctx.ca:], None
 
 
+class _CatPrefilledFn(torch.autograd.Function):
+    """concat(a, b) where BOTH operands were written by their producers into channel slices of `buf` (a: buf[..., :Ca] -- an encoder
+    block wrote its output there, see skip_buffer; b: buf[..., Ca:]): no copy at all.  The gradient splits into two channel-slice views."""
+    @staticmethod
+    def forward(ctx, a, b, buf):
+        ca = a.shape[-1]
+        assert a.data_ptr() == buf.data_ptr() and b.data_ptr() == buf[..., ca:].data_ptr() and buf.shape[-1] == ca + b.shape[-1]
+        assert a.stride(3) == buf.stride(3) and b.stride(3) == buf.stride(3)
+        ctx.ca = ca
+        return alias_channels(buf, 0, buf.shape[-1])
+
+    @staticmethod
+    def backward(ctx, d):
+        return d[..., :ctx.ca], d[..., ctx.ca:], None
+
+
+def alias_channels(buf, c0, c1):
+    """buf[..., c0:c1] as a tensor of its OWN (same storage, no autograd view relation, its own version counter): the kernels address memory
+    by pointer and stride, and the producers / consumers of the slices are ordered by their autograd Functions; a real view would tie the
+    slices' version counters together and make autograd reject the carried aliases of one slice once the other slice is written."""
+    n, d, h, w, ct = buf.shape
+    t = torch.empty(0, dtype=buf.dtype, device=buf.device)
+    t.set_(buf.untyped_storage(), buf.storage_offset() + c0, (n, d, h, w, c1 - c0), buf.stride())
+    return t
+
+
+def skip_buffer(n, d, h, w, c, cb, device):
+    """[N,D,H,W,c+cb] buffer for a skip connection: the encoder block that produces the skip tensor writes it into channels [0, c) (conv(...,
+    out=alias_channels(buf, 0, c))), the decoder's transposed conv into [c, c+cb) -- the concatenation of cls_wise_former.py:716-729 costs
+    no copy (the full-resolution one was 268 MB read + written per step)."""
+    return torch.empty((n, d, h, w, c + cb), dtype=torch.float32, device=device)
+
+
 def cat_buffer(a, cb):
     """an uninitialised [N,D,H,W,Ca+cb] buffer for cat_into; hand buf[..., Ca:] to the producer of the second operand"""
     return torch.empty(a.shape[:-1] + (a.shape[-1] + cb,), dtype=torch.float32, device=a.device)
 
 
 def cat_into(a, b, buf):
+    if a.data_ptr() == buf.data_ptr() and a.stride(3) == buf.stride(3):      # a already lives in buf (skip_buffer)
+        return _CatPrefilledFn.apply(a, b, buf)
     return _CatIntoFn.apply(a, b, buf)
 
 

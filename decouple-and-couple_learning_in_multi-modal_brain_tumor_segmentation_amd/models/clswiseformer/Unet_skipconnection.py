@@ -35,9 +35,17 @@ class EnBlock(nn.Module):
         self.conv1 = HipConv(in_channels, in_channels)
         self.conv2 = HipConv(in_channels, in_channels)
 
-    def forward(self, x, x_stats, want_stats=True):
+    def forward(self, x, x_stats, want_stats=True, skip_cb=0):
         # carry: the residual's gradient returns to conv1's backward and is added inside the kernel that writes dx
         h, hs, xc = self.conv1(x, in_norm=x_stats, slope=0.0, want_stats=True, carry=True)
+        if skip_cb:
+            # this block's output is a skip tensor: it is written straight into the lower channels of the buffer the decoder will
+            # concatenate in (CF.skip_buffer), so that concatenation costs no copy
+            n, d, hh, w, c = h.shape
+            buf = CF.skip_buffer(n, d, hh, w, c, skip_cb, h.device)
+            y, st = self.conv2(h, in_norm=hs, slope=0.0, residual=xc, want_stats=want_stats, out=CF.alias_channels(buf, 0, c))
+            y._cwf_catbuf = buf
+            return y, st
         return self.conv2(h, in_norm=hs, slope=0.0, residual=xc, want_stats=want_stats)
 
 
@@ -67,15 +75,17 @@ class Unet(nn.Module):
         self.EnBlock4_1 = EnBlock(8 * c)
         self.EnBlock4_2 = EnBlock(8 * c)
         self.EnDown_4 = EnDown(8 * c, 16 * c, stride=1)
+        # channels the decoder concatenates behind the level-1 / level-2 skip tensors (DeUp_Cat: as many as the skip has; 0 = plain tensors)
+        self.skip_cat = (c, 2 * c)
 
     def forward(self, x, stem_keep=None):
         x, s = self.InitConv(x, stem_keep)
         x, s = self.EnBlock1(x, s)
-        x1, _ = self.EnBlock1_1(x, s, want_stats=False)
+        x1, _ = self.EnBlock1_1(x, s, want_stats=False, skip_cb=self.skip_cat[0])
         # the skip connections leave through the carry alias of the down-sampling conv (their gradient is folded into its dgrad)
         x, s, x1 = self.EnDown1(x1, carry=True)
         x, s = self.EnBlock2_1(x, s)
-        x2, _ = self.EnBlock2_2(x, s, want_stats=False)
+        x2, _ = self.EnBlock2_2(x, s, want_stats=False, skip_cb=self.skip_cat[1])
         x, s, x2 = self.EnDown2(x2, carry=True)
         x, s = self.EnBlock3_1(x, s)
         x3, _ = self.EnBlock3_2(x, s, want_stats=False)

@@ -248,8 +248,11 @@ class DeUp_Cat(nn.Module):
 
     def forward(self, x, prev):
         t, _ = self.conv1(x)
-        buf = CF.cat_buffer(prev, self.conv2.spec.cout)
-        u, _ = self.conv2(t, out=buf[..., prev.shape[-1]:])       # the transposed conv writes its half of the concatenation in place
+        buf = getattr(prev, "_cwf_catbuf", None)              # the encoder wrote the skip tensor into its concatenation buffer already
+        if buf is None or buf.shape[-1] != prev.shape[-1] + self.conv2.spec.cout or buf.data_ptr() != prev.data_ptr():
+            buf = CF.cat_buffer(prev, self.conv2.spec.cout)
+        hi = buf[..., prev.shape[-1]:] if buf.data_ptr() != prev.data_ptr() else CF.alias_channels(buf, prev.shape[-1], buf.shape[-1])
+        u, _ = self.conv2(t, out=hi)                              # the transposed conv writes its half of the concatenation in place
         y, _ = self.conv3(CF.cat_into(prev, u, buf))
         return y
 
