@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <queue>
@@ -184,11 +185,24 @@ extern "C" int cwf_plan_create(void* graph_, void** out) {
         int u = order[i];
         for (int v : succ[u]) depth[u] = std::max(depth[u], depth[v] + 1);
     }
+    // The weight-gradient chain is recognised by its kernels (weight-gradient kernels, their operand conversions and slab reduces):
+    // those nodes ALWAYS go to stream 1, the low-priority stream, wherever the capture had them, and take no part in the chain
+    // logic of the other nodes -- a structural guess that put them on a high-priority stream, or the main chain on the low-priority
+    // one, cost 30-40 % of the step (any assignment is correct; the events below carry every cross-stream edge).
+    std::vector<char> side(n, 0);
+    bool any_side = false;
+    for (size_t i = 0; i < n; ++i) {
+        const PlanNode& N = P->nodes[i];
+        if (N.kind != NK_KERNEL) continue;
+        const char* nm = hipKernelNameRefByPtr(N.kp.func, nullptr);
+        if (nm && (strstr(nm, "wgrad") || strstr(nm, "to_bf16_kernel"))) { side[order[i]] = 1; any_side = true; }
+    }
+    (void)hipGetLastError();
     std::vector<int> heir(n, -1);
     for (size_t u = 0; u < n; ++u) {
         int best = -1;
         for (int v : succ[u]) {
-            if (P->nodes[pos[v]].kind == NK_MARKER) continue;
+            if (P->nodes[pos[v]].kind == NK_MARKER || side[v]) continue;
             if (best < 0) { best = v; continue; }
             const bool sv = pred[v].size() == 1, sb = pred[best].size() == 1;
             if (sv != sb) { if (sv) best = v; continue; }
@@ -200,26 +214,29 @@ extern "C" int cwf_plan_create(void* graph_, void** out) {
     int waited[MAX_STREAMS + 1][MAX_STREAMS];                 // [waiting stream (MAX_STREAMS = marker stream)][source] -> last position waited for
     for (auto& row : waited) for (int& w : row) w = -1;
     std::vector<int> stream_of(n, -2);
-    int n_streams = 1;
+    int n_streams = any_side ? 2 : 1;                      // stream 1 is reserved for the weight-gradient chain
     bool any = false;
     for (size_t i = 0; i < n; ++i) {
         int v = order[i];
         PlanNode& N = P->nodes[i];
         if (N.kind == NK_MARKER) {
             N.stream = -1;
+        } else if (side[v]) {
+            N.stream = 1;
+            tail[1] = v;
         } else {
             int s = -1;
             for (int p : pred[v]) {
                 int sp = stream_of[p];
-                if (sp >= 0 && tail[sp] == p && heir[p] == v && (s < 0 || sp < s)) s = sp;
+                if (sp >= 0 && sp != 1 && tail[sp] == p && heir[p] == v && (s < 0 || sp < s)) s = sp;
             }
             if (s < 0 && !any) s = 0;
-            for (int c = 1; s < 0 && c < n_streams; ++c) {
+            for (int c = 2; s < 0 && c < n_streams; ++c) {
                 int t = tail[c];
                 if (t < 0 || heir[t] < 0 || pos[heir[t]] < (int)i) s = c;         // that chain has ended
             }
-            if (s < 0 && n_streams < MAX_STREAMS) s = n_streams++;
-            if (s < 0) s = 1;
+            if (s < 0 && n_streams < MAX_STREAMS) { if (n_streams < 2) n_streams = 2; s = n_streams++; }
+            if (s < 0) s = 0;
             N.stream = s;
             tail[s] = v;
             any = true;
