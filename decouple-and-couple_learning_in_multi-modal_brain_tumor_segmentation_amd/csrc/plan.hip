@@ -195,7 +195,9 @@ extern "C" int cwf_plan_create(void* graph_, void** out) {
         const PlanNode& N = P->nodes[i];
         if (N.kind != NK_KERNEL) continue;
         const char* nm = hipKernelNameRefByPtr(N.kp.func, nullptr);
-        if (nm && (strstr(nm, "wgrad") || strstr(nm, "to_bf16_kernel"))) { side[order[i]] = 1; any_side = true; }
+        // (+ the bias-gradient sums of the transposed convs: in_reduce_kernel<0> + stats_channel_sum_kernel, cwf.kernels.channel_sum_to)
+        if (nm && (strstr(nm, "wgrad") || strstr(nm, "to_bf16_kernel") || strstr(nm, "stats_channel_sum_kernel") ||
+                   strstr(nm, "in_reduce_kernelILi0") || strstr(nm, "in_reduce_kernel<0"))) { side[order[i]] = 1; any_side = true; }
     }
     (void)hipGetLastError();
     std::vector<int> heir(n, -1);

@@ -36,6 +36,9 @@ struct WgArgsB {
   // x / dy / slab buffer; single-class (3x3x3 stride-1) operators only.  groups == 0: an ordinary launch (blockIdx.z = class)
   int groups;
   const float* x_g[3]; const float* dy_g[3]; float* partial_g[3];
+  // wgrad16_kernel only: dy is used as dy * dy_scale[n][co] (the per-(sample, channel) scale of a dropout3d behind the conv, InitConv:
+  // Unet_skipconnection.py:29-33 -- its backward is a full-resolution elementwise pass otherwise, the last one before the optimizer)
+  const float* dy_scale;
 };
 
 __device__ __forceinline__ unsigned pack_bf16w(float a, float b) {
@@ -655,6 +658,8 @@ __global__ __launch_bounds__(256 + 64 * W16_LW) void wgrad16_kernel(const WgArgs
         sc = *reinterpret_cast<const float4*>(a.in_scale + (int64_t)n * g.Cin + c);
         sh = *reinterpret_cast<const float4*>(a.in_shift + (int64_t)n * g.Cin + c);
       }
+      float4 dsc = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (a.dy_scale) dsc = *reinterpret_cast<const float4*>(a.dy_scale + (int64_t)(tc / tiles_sp) * g.Cout + c);
       unsigned short* xh = lds + buf * BUF;
       unsigned short* xl = xh + XI;
       unsigned short* dh = lds + buf * BUF + XI * (X3 ? 2 : 1);
@@ -687,7 +692,8 @@ __global__ __launch_bounds__(256 + 64 * W16_LW) void wgrad16_kernel(const WgArgs
 #pragma unroll
         for (int i = 0; i < W16_DS; ++i) {
           if (i == W16_DS - 1 && !dlast_ok) continue;
-          const float4 val = pd[SET][i];
+          float4 val = pd[SET][i];
+          val.x *= dsc.x; val.y *= dsc.y; val.z *= dsc.z; val.w *= dsc.w;
           uint2 h, l;
           if (X3) { split2(val.x, val.y, h.x, l.x); split2(val.z, val.w, h.y, l.y); } else { h.x = pk_bf16(val.x, val.y); h.y = pk_bf16(val.z, val.w); }
           if (!ALLIN) {
@@ -1503,7 +1509,16 @@ extern "C" int64_t cwf_wgrad_slab_floats(int op, int Cin, int Cout);
 static int wgrad_bf16_impl(int op, int x3, const float* x, int x_ldc, const float* in_scale, const float* in_shift, float in_slope,
                            const float* dy, int dy_ldc, float* partial,
                            int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int* nsplit_used, void* stream,
-                           int groups, const float* const* xg, const float* const* dyg, float* const* pg);
+                           int groups, const float* const* xg, const float* const* dyg, float* const* pg, const float* dy_scale = nullptr);
+
+// cwf_wgrad_mfma_bf16 with dy taken as dy * dy_scale[n][co] (full-resolution 16-output-channel 3x3x3 stride-1 layers only: the stem)
+extern "C" int cwf_wgrad_mfma_bf16_dys(int op, int x3, const float* x, int x_ldc, const float* in_scale, const float* in_shift, float in_slope,
+                                       const float* dy, int dy_ldc, const float* dy_scale, float* partial,
+                                       int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int* nsplit_used, void* stream) {
+  if (!dy_scale) return CWF_E_BADARG;
+  return wgrad_bf16_impl(op, x3, x, x_ldc, in_scale, in_shift, in_slope, dy, dy_ldc, partial, N, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, nsplit_used, stream,
+                         0, nullptr, nullptr, nullptr, dy_scale);
+}
 
 extern "C" int cwf_wgrad_mfma_bf16(int op, int x3, const float* x, int x_ldc, const float* in_scale, const float* in_shift, float in_slope,
                                    const float* dy, int dy_ldc, float* partial,
@@ -1528,8 +1543,11 @@ extern "C" int cwf_wgrad_mfma_bf16_grouped(int op, int x3, const float* const* h
 static int wgrad_bf16_impl(int op, int x3, const float* x, int x_ldc, const float* in_scale, const float* in_shift, float in_slope,
                            const float* dy, int dy_ldc, float* partial,
                            int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int* nsplit_used, void* stream,
-                           int groups, const float* const* xg, const float* const* dyg, float* const* pg) {
+                           int groups, const float* const* xg, const float* const* dyg, float* const* pg, const float* dy_scale) {
   if (!x || !dy || !partial || N <= 0) return CWF_E_BADARG;
+  // dy_scale is implemented by wgrad16_kernel alone
+  if (dy_scale && !(!groups && op == CWF_CONV3_S1 && Cin <= 16 && Cout == 16 && (dy_ldc & 3) == 0 && (((uintptr_t)dy) & 15) == 0 && (int64_t)Do * Ho * Wo >= 32768))
+    return CWF_E_BADARG;
   if ((Cin & 3) || (x_ldc & 3) || ((uintptr_t)x & 15) || ((uintptr_t)partial & 15)) return CWF_E_ALIGN;
   if (in_scale && !in_shift) return CWF_E_BADARG;
   if (!(op == CWF_CONV3_S1 || op == CWF_CONV3_S2 || op == CWF_CONV1 || op == CWF_CONVT2)) return CWF_E_BADARG;
@@ -1553,7 +1571,7 @@ static int wgrad_bf16_impl(int op, int x3, const float* x, int x_ldc, const floa
     return CWF_E_BADARG;
   a.x = x; a.in_scale = in_scale; a.in_shift = in_shift; a.in_slope = in_slope; a.dy = dy; a.dy_ldc = dy_ldc; a.partial = partial;
   a.ngroups = ngroups; a.tiles_per_split = tps; a.total_tiles = total; a.slab_floats = blocks * 256;
-  a.groups = groups;
+  a.groups = groups; a.dy_scale = dy_scale;
   bool dy_al = (((uintptr_t)dy) & 15) == 0;
   for (int q = 0; q < 3; ++q) {
     a.x_g[q] = (groups && q < groups) ? xg[q] : nullptr; a.dy_g[q] = (groups && q < groups) ? dyg[q] : nullptr; a.partial_g[q] = (groups && q < groups) ? pg[q] : nullptr;

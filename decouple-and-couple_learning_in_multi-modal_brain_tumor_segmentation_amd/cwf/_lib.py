@@ -38,6 +38,7 @@ SIGNATURES = {
     "cwf_norm_act_add_ex": [P, I, P, P, F, P, I, P, I, P, I, L, I, P],
     "cwf_to_bf16": [P, I, P, P, F, P, I, L, I, P],
     "cwf_wgrad16_bf16": [P, P, P, P, I, I, I, I, P, P],
+    "cwf_wgrad_mfma_bf16_dys": [I, I, P, I, P, P, F, P, I, P, P, I, I, I, I, I, I, I, I, I, P, P],
     "cwf_wgrad_s1_bf16": [P, P, P, P, I, I, I, I, I, I, P, P],
     "cwf_conv_mfma_bf16_in16": [I, P, P, P, P, P, I, P, I, P, P, I, P, P, F, I, I, I, I, P],
     "cwf_gemm": [P, L, L, L, L, P, L, L, L, L, P, L, L, L, P, P, L, L, L, I, I, I, I, I, F, I, I, P],

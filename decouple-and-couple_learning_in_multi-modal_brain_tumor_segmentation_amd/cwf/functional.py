@@ -218,8 +218,18 @@ class _ConvFn(torch.autograd.Function):
             return (dcarry,) + (None,) * 14
         x, w, in_scale, in_shift, out_scale = ctx.saved_tensors
         spec = ctx.spec
+        dys = None
         if out_scale is not None:
-            dy = K.channel_scale(_dy_f32(K, dy), out_scale)
+            sink0 = active_sink()
+            fold = (sink0 is not None and not ctx.needs_input_grad[0] and not ctx.has_res and spec.uses <= 1 and ctx.needs_input_grad[1] and
+                    sink0.view(w) is not None and (ctx.bias_ref is None or sink0.view(ctx.bias_ref) is not None) and
+                    getattr(K, "dy_scale_ok", lambda *a: False)(spec.op, spec.cin, spec.cout, dy.shape[1] * dy.shape[2] * dy.shape[3])
+                    and dy.shape[-1] == spec.cout and dy.is_contiguous())
+            if fold:
+                dys = out_scale                       # the weight gradient (the only reader of dy here) scales dy while staging it
+                dy = _dy_f32(K, dy)
+            else:
+                dy = K.channel_scale(_dy_f32(K, dy), out_scale)
         dres = dy if ctx.has_res else None
         dy_private = not ctx.has_res
         if ctx.has_res and ctx.res_link is not None:
@@ -286,12 +296,17 @@ class _ConvFn(torch.autograd.Function):
             # gradient-sink path (Trainer): slabs now, ONE batched reduce per backward phase writes dW / db into the flat buffer
             dyv = dy[..., :spec.cout] if dy.shape[-1] != spec.cout else dy
             kw = dict(x16=xa16, dy16=dy16) if (use16 and (xa16 is not None or dy16 is not None)) else {}
+            if dys is not None:
+                kw["dy_scale"] = dys
             K.wgrad_to(spec, spec.op, x, in_scale, in_shift, ctx.slope, dyv, spec.cout, spec.inv_map, sw, sb if spec.has_bias_map else None,
                        allow_async=dy_private, **kw)
             sink.mark(w)
             if sb is not None:
                 if not spec.has_bias_map:   # ConvTranspose: the bias gradient spans the 8 parity classes
-                    K.stats_channel_sum(K.in_stats(dy), sb)
+                    if hasattr(K, "channel_sum_to"):
+                        K.channel_sum_to(dy, sb, allow_async=dy_private)      # (a full pass over dy: on the weight-gradient side stream)
+                    else:
+                        K.stats_channel_sum(K.in_stats(dy), sb)
                 sink.mark(ctx.bias_ref)
         elif ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dyv = dy[..., :spec.cout] if dy.shape[-1] != spec.cout else dy

@@ -443,22 +443,41 @@ class HipBackend:
                 self._wgrad_to_impl(*args)
         self._wg_keep.extend(held)
 
-    def wgrad_to(self, key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec=None, x16=None, dy16=None, allow_async=False):
+    def channel_sum_to(self, dy, out, allow_async=False):
+        """out[c] = sum over (n, voxels) of dy[..., c] (the bias gradient of a layer whose slabs carry no bias row): a full pass over
+        dy that only the optimizer waits for -- on the weight-gradient side stream when that is in use."""
+        if self.wgrad_async and allow_async:
+            side = self.wgrad_stream(dy.device)
+            side.wait_stream(torch.cuda.current_stream(dy.device))
+            with torch.cuda.stream(side):
+                self.stats_channel_sum(self.in_stats(dy), out)
+            dy.record_stream(side)
+        else:
+            self.stats_channel_sum(self.in_stats(dy), out)
+            self._wg_sync_needed = self.wgrad_async
+
+    def dy_scale_ok(self, op, cin, cout, nvox):
+        """wgrad_to(..., dy_scale=) is implemented for this layer (the full-resolution kernel of the <= 16 -> 16 layers, bf16 modes)"""
+        return op == pk.CONV3_S1 and cin <= 16 and cout == 16 and nvox >= 32768 and (_WGRAD_PRECISION or _PRECISION) != "fp32" and \
+            not self.bf16_operands_ok(op, cin, cout, nvox)
+
+    def wgrad_to(self, key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec=None, x16=None, dy16=None, dy_scale=None,
+                 allow_async=False):
         """x16 / dy16: bf16 operand images (see bf16_operands_ok).  Given one of them for an eligible layer, the other is made by a
         conversion pass in front of the launch (on the stream the launch runs on); x / dy are then not read."""
         if self.wgrad_async and allow_async and self.wgrad_defer:
-            self._wg_held.append((key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec, x16, dy16))
+            self._wg_held.append((key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec, x16, dy16, dy_scale))
             return
         if self.wgrad_async and allow_async:
             side = self.wgrad_stream(x.device)
             side.wait_stream(torch.cuda.current_stream(x.device))
             with torch.cuda.stream(side):
-                self._wgrad_to_impl(key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec, x16, dy16)
-            for t in (x, dy, in_scale, in_shift, x16, dy16):
+                self._wgrad_to_impl(key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec, x16, dy16, dy_scale)
+            for t in (x, dy, in_scale, in_shift, x16, dy16, dy_scale):
                 if t is not None:
                     t.record_stream(side)
         else:
-            self._wgrad_to_impl(key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec, x16, dy16)
+            self._wgrad_to_impl(key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec, x16, dy16, dy_scale)
             self._wg_sync_needed = self.wgrad_async          # a main-stream producer: the side-stream reduce must wait for it
         if len(self._wg_pending) >= self.flush_every:
             # reduce in instalments: the LAST reduce of backward (after the stem's weight gradient) is exposed before the optimizer
@@ -466,7 +485,7 @@ class HipBackend:
             # the descriptor tables are keyed by their rows and must already exist when the capture runs.)
             self.wgrad_flush(x.device)
 
-    def _wgrad_to_impl(self, key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec, x16=None, dy16=None):
+    def _wgrad_to_impl(self, key, op, x, in_scale, in_shift, slope, dy, cout, inv_map, dw_dst, db_dst, prec, x16=None, dy16=None, dy_scale=None):
         x, x_ldc = cl(x)
         dy, dy_ldc = cl(dy)
         n, di, hi, wi, cin = x.shape
@@ -498,6 +517,12 @@ class HipBackend:
             else:
                 self._call("cwf_wgrad_s1_bf16", x16.data_ptr(), dy16.data_ptr(), self.zero16(x.device).data_ptr(), part.data_ptr(),
                            n, di, hi, wi, cin, cout, ctypes.addressof(used), self._stream())
+            nsplit = used.value
+        elif dy_scale is not None:
+            used = ctypes.c_int(0)
+            self._call("cwf_wgrad_mfma_bf16_dys", op, 1 if mode == "bf16x3" else 0, x.data_ptr(), x_ldc, _p(in_scale), _p(in_shift),
+                       float(slope), dy.data_ptr(), dy_ldc, dy_scale.data_ptr(), part.data_ptr(), n, di, hi, wi, cin, do, ho, wo, cout,
+                       ctypes.addressof(used), self._stream())
             nsplit = used.value
         elif mode == "fp32":
             self._call("cwf_wgrad_mfma", op, x.data_ptr(), x_ldc, _p(in_scale), _p(in_shift), float(slope),

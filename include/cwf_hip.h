@@ -184,6 +184,12 @@ int cwf_conv_mfma_bf16_in16(int op, const void* x16, const void* zero16, const v
 int cwf_wgrad16_bf16(const void* xa16, const void* dy16, const void* zero16, float* partial,
                      int N, int D, int H, int W, int* nsplit_used, void* stream);
 
+/* cwf_wgrad_mfma_bf16 with dy taken as dy * dy_scale[n][co] -- the backward of the always-on dropout3d behind InitConv
+ * (Unet_skipconnection.py:29-33) folded into the stem's weight gradient; CWF_CONV3_S1 layers with Cin <= 16, Cout = 16 and
+ * >= 32768 voxels only (CWF_E_BADARG otherwise). */
+int cwf_wgrad_mfma_bf16_dys(int op, int x3, const float* x, int x_ldc, const float* in_scale, const float* in_shift, float in_slope,
+                            const float* dy, int dy_ldc, const float* dy_scale, float* partial,
+                            int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int* nsplit_used, void* stream);
 /* The same for the 3x3x3 stride-1 layers with Cin a multiple of 16 (>= 32) and Cout a multiple of 32 (EnBlock2/3/4, DeBlock3/4, Enblock8,
  * decouplers; Unet_skipconnection.py:36-57, cls_wise_former.py:691-754): xa16 [N][D][H][W][Cin], dy16 [N][D][H][W][Cout] bf16.
  * Slab layout and reduction: cwf_wgrad_mfma_bf16(CWF_CONV3_S1, Cin, Cout) / cwf_wgrad_reduce. */
