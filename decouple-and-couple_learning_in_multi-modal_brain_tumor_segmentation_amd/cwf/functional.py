@@ -194,6 +194,9 @@ class _ConvFn(torch.autograd.Function):
             # InstanceNorm-backward apply pass (which matters for the last layers of backward: nothing is left to hide behind)
             ctx.x16 = K.to_bf16_side(x, in_scale, in_shift, slope)
         ctx.up16 = getattr(x, "_cwf_want16", False)     # x's producer is such a layer: hand its gradient on with a bf16 image ("only": nothing else)
+        # the LAST layers of backward: nothing is left to hide their weight gradient behind, so it must not wait for this layer's own data
+        # gradient + apply pass (which would deliver xa16): it is issued first and converts x itself on the side stream
+        ctx.wgrad_first = bool(getattr(x, "_cwf_wgrad_first", False))
         ctx.save_for_backward(x, w, in_scale, in_shift, out_scale)
         # carry: x is handed on as a second output (an alias).  Whatever consumes that alias (a residual connection, a skip
         # connection) sends its gradient back HERE, where it is folded into the kernel that writes dx (dx_add of the
@@ -253,6 +256,27 @@ class _ConvFn(torch.autograd.Function):
         if not use16:
             dy16 = None
         xa16 = ctx.x16 if use16 else None
+
+        def issue_sink_wgrad(xa16_):
+            # gradient-sink path (Trainer): slabs now, ONE batched reduce per backward phase writes dW / db into the flat buffer
+            dyv = dy[..., :spec.cout] if dy.shape[-1] != spec.cout else dy
+            kw = dict(x16=xa16_, dy16=dy16) if (use16 and (xa16_ is not None or dy16 is not None)) else {}
+            if dys is not None:
+                kw["dy_scale"] = dys
+            K.wgrad_to(spec, spec.op, x, in_scale, in_shift, ctx.slope, dyv, spec.cout, spec.inv_map, sw, sb if spec.has_bias_map else None,
+                       allow_async=dy_private, **kw)
+            sink.mark(w)
+            if sb is not None:
+                if not spec.has_bias_map:   # ConvTranspose: the bias gradient spans the 8 parity classes
+                    if hasattr(K, "channel_sum_to"):
+                        K.channel_sum_to(dy, sb, allow_async=dy_private)      # (a full pass over dy: on the weight-gradient side stream)
+                    else:
+                        K.stats_channel_sum(K.in_stats(dy), sb)
+                sink.mark(ctx.bias_ref)
+
+        early = to_sink and use16 and ctx.wgrad_first
+        if early:
+            issue_sink_wgrad(xa16)
         if ctx.needs_input_grad[0]:
             dxa = torch.empty(x.shape, dtype=torch.float32, device=x.device)
             fused = in_scale is not None and getattr(K, "supports_fused_norm_bwd", lambda: False)()
@@ -263,7 +287,7 @@ class _ConvFn(torch.autograd.Function):
                 K.conv(pk.dgrad_op(spec.op), dy, spec.packed(True), None, spec.cin, out=dxa, w_ref=w, fwd_op=spec.op,
                        stats=sums, nb=(x, in_scale, in_shift, ctx.slope), **kw16)
                 emits = getattr(K, "APPLY_EMITS", ())
-                want_xa, want_dx = use16 and "xa" in emits, ctx.up16 and "dx" in emits
+                want_xa, want_dx = use16 and "xa" in emits and not early, ctx.up16 and "dx" in emits
                 if want_xa or want_dx:
                     # the apply pass has x, its statistics and dx in registers: it also writes this layer's weight-gradient operand
                     # bf16(act(IN(x))) and the bf16 image of dx for the layer that produced x -- and ONLY that image where the layer
@@ -293,21 +317,8 @@ class _ConvFn(torch.autograd.Function):
         elif dcarry is not None:
             dx = dcarry
         if to_sink:
-            # gradient-sink path (Trainer): slabs now, ONE batched reduce per backward phase writes dW / db into the flat buffer
-            dyv = dy[..., :spec.cout] if dy.shape[-1] != spec.cout else dy
-            kw = dict(x16=xa16, dy16=dy16) if (use16 and (xa16 is not None or dy16 is not None)) else {}
-            if dys is not None:
-                kw["dy_scale"] = dys
-            K.wgrad_to(spec, spec.op, x, in_scale, in_shift, ctx.slope, dyv, spec.cout, spec.inv_map, sw, sb if spec.has_bias_map else None,
-                       allow_async=dy_private, **kw)
-            sink.mark(w)
-            if sb is not None:
-                if not spec.has_bias_map:   # ConvTranspose: the bias gradient spans the 8 parity classes
-                    if hasattr(K, "channel_sum_to"):
-                        K.channel_sum_to(dy, sb, allow_async=dy_private)      # (a full pass over dy: on the weight-gradient side stream)
-                    else:
-                        K.stats_channel_sum(K.in_stats(dy), sb)
-                sink.mark(ctx.bias_ref)
+            if not early:
+                issue_sink_wgrad(xa16)
         elif ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dyv = dy[..., :spec.cout] if dy.shape[-1] != spec.cout else dy
             # side-stream weight gradients only where nothing on the main stream can touch their operands or results early:

@@ -24,7 +24,9 @@ class InitConv(nn.Module):
         if keep is None and self.dropout > 0.0:
             p = self.dropout
             keep = CF.dropout_mask((x.shape[0], self.conv.spec.cout), p, x.device)      # HIP kernel over the device generator state
-        return self.conv(x, out_scale=keep, want_stats=True)
+        y, st = self.conv(x, out_scale=keep, want_stats=True)
+        y._cwf_wgrad_first = True        # the conv that reads the stem's output runs the last data gradient of backward (cwf.functional)
+        return y, st
 
 
 class EnBlock(nn.Module):
