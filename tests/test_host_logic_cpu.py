@@ -161,3 +161,35 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     unbound = [n for n in declared if n not in bound]
     assert not unbound, unbound
     assert lib.cwf_version() >= 2
+
+
+def test_carry_link_routes_the_residual_gradient_and_sums_other_consumers(emul_backend):
+    """functional.CarryLink: a conv that takes a carried alias as its residual hands dL/d(residual) to the producing conv's backward
+    directly (autograd sees None for it); a SECOND consumer of the alias still reaches that backward through autograd and the two are
+    added there.  Gradients must equal plain torch autograd on the same graph; the skip-buffer aliasing (alias_channels) must not trip
+    autograd's view checks."""
+    import torch.nn.functional as F
+    from cwf import functional as CF, packing as pk
+    torch.manual_seed(3)
+    n, d, c = 1, 6, 8
+    x = torch.randn(n, d, d, d, c, requires_grad=True)
+    w1 = torch.randn(c, c, 3, 3, 3, requires_grad=True) * 0.1
+    w2 = torch.randn(c, c, 3, 3, 3, requires_grad=True) * 0.1
+    w1.retain_grad(); w2.retain_grad()
+    b1 = torch.zeros(c, requires_grad=True); b2 = torch.zeros(c, requires_grad=True)
+    s1, s2 = CF.ConvSpec(pk.CONV3_S1, c, c), CF.ConvSpec(pk.CONV3_S1, c, c)
+    buf = CF.skip_buffer(n, d, d, d, c, c, x.device)
+    h, _, xc = CF.conv(x, w1, b1, s1, carry=True)
+    assert getattr(xc, "_cwf_carry", None) is not None
+    y, _ = CF.conv(h, w2, b2, s2, residual=xc, out=CF.alias_channels(buf, 0, c))      # the residual's gradient travels through the link
+    loss = (y * y).sum() + (xc * 0.5).sum()                                            # ... and a second consumer of the alias through autograd
+    loss.backward()
+    # reference: the same graph in plain torch ops (NCDHW)
+    xr = x.detach().permute(0, 4, 1, 2, 3).clone().requires_grad_(True)
+    w1r, w2r = w1.detach().clone().requires_grad_(True), w2.detach().clone().requires_grad_(True)
+    hr = F.conv3d(xr, w1r, None, padding=1)
+    yr = F.conv3d(hr, w2r, None, padding=1) + xr
+    ((yr * yr).sum() + (xr * 0.5).sum()).backward()
+    assert torch.allclose(x.grad.permute(0, 4, 1, 2, 3), xr.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(w1.grad, w1r.grad, rtol=1e-4, atol=1e-5) and torch.allclose(w2.grad, w2r.grad, rtol=1e-4, atol=1e-5)
+    assert y.data_ptr() == buf.data_ptr() and torch.equal(buf[..., :c], y.detach())
