@@ -188,7 +188,7 @@ class _ConvFn(torch.autograd.Function):
         ctx.use16 = bool(ok16 is not None and ok16(spec.op, spec.cin, spec.cout, y.shape[1] * y.shape[2] * y.shape[3]))
         ctx.x16 = getattr(x, "_cwf16x", None) if (ctx.use16 and in_scale is None) else None     # bf16(x) from x's producer (a block tail)
         if ctx.use16 and ctx.x16 is None and ctx.needs_input_grad[1] and getattr(K, "wgrad_async", False) and \
-                getattr(K, "xa16_in_forward", False):            # (wgrad_async: a Trainer step -- the gradient-sink path will run)
+                (getattr(K, "xa16_in_forward", False) or (getattr(x, "_cwf_wgrad_first", False) and _FIRST_X16_FWD)):   # (wgrad_async: a Trainer step)
             # the weight-gradient operand bf16(act(IN(x))) depends on forward data only: made NOW, on the weight-gradient side stream,
             # which idles during the forward pass -- the backward pass then neither converts it nor waits for this layer's own
             # InstanceNorm-backward apply pass (which matters for the last layers of backward: nothing is left to hide behind)
@@ -392,6 +392,8 @@ def fused_conv3(x, convs, spec):
 # forward).  Only then may a backward pass leave the fp32 gradient of such a tensor unwritten and hand on its bf16 image alone
 # (autograd would otherwise add the unwritten buffer to another consumer's gradient).
 _SINGLE_CONSUMER = False
+import os as _os
+_FIRST_X16_FWD = _os.environ.get("CWF_FIRST_X16_FWD", "1") != "0"     # the layer behind the stem: its xa16 is made in the forward pass (side stream)
 
 
 def set_single_consumer_graph(flag: bool):
