@@ -196,10 +196,24 @@ extern "C" int cwf_plan_create(void* graph_, void** out) {
         if (N.kind != NK_KERNEL) continue;
         const char* nm = hipKernelNameRefByPtr(N.kp.func, nullptr);
         // (+ the bias-gradient sums of the transposed convs: in_reduce_kernel<0> + stats_channel_sum_kernel, cwf.kernels.channel_sum_to)
-        if (nm && (strstr(nm, "wgrad") || strstr(nm, "to_bf16_kernel") || strstr(nm, "stats_channel_sum_kernel") ||
+        if (nm && (strstr(nm, "wgrad") || strstr(nm, "stats_channel_sum_kernel") ||
                    strstr(nm, "in_reduce_kernelILi0") || strstr(nm, "in_reduce_kernel<0"))) { side[order[i]] = 1; any_side = true; }
+        else if (nm && strstr(nm, "to_bf16_kernel")) side[order[i]] = 2;      // decided below: a conversion belongs where its readers are
     }
     (void)hipGetLastError();
+    for (int i = (int)n - 1; i >= 0; --i) {               // (reverse topological order: a conversion feeding a conversion is handled too)
+        const int u = order[i];
+        if (side[u] != 2) continue;
+        bool all_side = !succ[u].empty();
+        for (int v : succ[u]) all_side = all_side && side[v] == 1;
+        side[u] = all_side ? 1 : 0;
+        any_side = any_side || all_side;
+    }
+    // Everything that is not part of the weight-gradient chain stays on the caller's stream, in the order the host issued it (a valid
+    // topological order: ties above are broken by creation index).  The chain logic below (CWF_PLAN_CHAINS=1) can spread independent
+    // branches over further streams, but on this runtime a third stream made every step 60 % SLOWER (three plan streams: 31 ms per
+    // step against 18), and a chain that breaks at a weight-gradient node would open one.
+    static const bool chains = getenv("CWF_PLAN_CHAINS") != nullptr;
     std::vector<int> heir(n, -1);
     for (size_t u = 0; u < n; ++u) {
         int best = -1;
@@ -226,6 +240,10 @@ extern "C" int cwf_plan_create(void* graph_, void** out) {
         } else if (side[v]) {
             N.stream = 1;
             tail[1] = v;
+        } else if (!chains) {
+            N.stream = 0;
+            tail[0] = v;
+            any = true;
         } else {
             int s = -1;
             for (int p : pred[v]) {

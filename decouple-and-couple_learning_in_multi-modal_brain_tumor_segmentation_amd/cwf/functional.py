@@ -248,6 +248,13 @@ class _ConvFn(torch.autograd.Function):
         to_sink = sw is not None and (ctx.bias_ref is None or sb is not None)
         use16 = ctx.use16 and to_sink and out_scale is None
         dy16 = getattr(dy, "_cwf16", None) if out_scale is None else None
+        if (_DY16_ON_MAIN and dy16 is None and use16 and ctx.needs_input_grad[0] and not getattr(dy, "_cwf_f32_missing", False) and
+                getattr(K, "bf16_dgrad_ok", lambda *a: False)(spec.op, spec.cin, spec.cout, dy.shape[1] * dy.shape[2] * dy.shape[3])
+                and dy.shape[-1] == spec.cout):
+            # no producer wrote the bf16 image of this gradient (it comes out of a stride-2 data gradient): one conversion pass HERE,
+            # on the main stream, serves both the data gradient (LDS-DMA form) and the weight gradient -- left to the weight gradient it
+            # runs on the side stream beside the HBM-bound end of backward (480 us instead of 65) and delays the optimizer
+            dy16 = K.to_bf16(dy)
         dg16 = dy16 if (dy16 is not None and getattr(K, "bf16_dgrad_ok", lambda *a: False)(
             spec.op, spec.cin, spec.cout, dy.shape[1] * dy.shape[2] * dy.shape[3])) else None     # the data gradient reads the bf16 image
         if getattr(dy, "_cwf_f32_missing", False) and not (use16 and dy16 is not None and (dg16 is not None or not ctx.needs_input_grad[0])
@@ -393,6 +400,7 @@ def fused_conv3(x, convs, spec):
 # (autograd would otherwise add the unwritten buffer to another consumer's gradient).
 _SINGLE_CONSUMER = False
 import os as _os
+_DY16_ON_MAIN = _os.environ.get("CWF_DY16_ON_MAIN", "0") != "0"     # (measured 0.3 % slower than leaving the conversion to the side stream)
 _FIRST_X16_FWD = _os.environ.get("CWF_FIRST_X16_FWD", "1") != "0"     # the layer behind the stem: its xa16 is made in the forward pass (side stream)
 
 

@@ -146,7 +146,10 @@ class Trainer:
         loss, parts = total_loss(outputs, target, edge)
         self.opt.zero_grad(set_to_none=True)
         if hasattr(K, "flush_every_default"):
-            K.flush_every = (1 << 30) if self.use_graph else K.flush_every_default   # (graph mode: one reduce per phase, in warm-up too)
+            # graph modes: one reduce per phase, in warm-up too (CWF_PLAN_FLUSH=N: instalments of N layers in plan mode as in eager mode --
+            # the descriptor tables are keyed by their rows, so the warm-up steps must already produce the capture's instalments)
+            pf = int(os.environ.get("CWF_PLAN_FLUSH", "0"))
+            K.flush_every = (pf if (pf > 0 and self.graph_mode == "plan") else (1 << 30)) if self.use_graph else K.flush_every_default
         if hasattr(K, "wgrad_release"):
             K.wgrad_defer = self.wgrad_async and self.defer_decoder_wgrad and hasattr(self.model, "phase_callback")
         self._in_backward = True

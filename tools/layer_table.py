@@ -61,7 +61,10 @@ for (op, cin, cout, ext, normed, wstats), mods in sorted(seen.items(), key=lambd
         # data gradient reads dy16 (conv16s IN16), the weight gradient xa16 and dy16 (wgrad16d); marked '*'
         dy16 = K.to_bf16(dyv); x16 = K.to_bf16(xin, sc if normed else None, sh if normed else None, 0.01)
         dwb = torch.zeros(w.numel(), device=dev); dbb = torch.zeros(cout, device=dev)
-        d = timeit(lambda: K.conv(pk.dgrad_op(op), dy, spec.packed(True), None, cin, out=dx, w_ref=w, fwd_op=op, x16=dy16))
+        if K.bf16_dgrad_ok(op, cin, cout, y.shape[1] * y.shape[2] * y.shape[3]):
+            d = timeit(lambda: K.conv(pk.dgrad_op(op), dy, spec.packed(True), None, cin, out=dx, w_ref=w, fwd_op=op, x16=dy16))
+        else:
+            d = timeit(lambda: K.conv(pk.dgrad_op(op), dy, spec.packed(True), None, cin, out=dx, w_ref=w, fwd_op=op))
         def wg_img():
             K._wgrad_to_impl(("lt", cin, cout, ext), op, xin, None, None, 1.0, dyv, cout, spec.inv_map, dwb, dbb, None, x16, dy16)
             K.wgrad_flush(dev)
