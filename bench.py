@@ -21,6 +21,8 @@ Rank 0 prints ONE JSON line with the contract fields plus
 import argparse
 import json
 import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before the first HIP call: see cwf/__init__.py (stream -> hardware-queue multiplexing)
 import sys
 import time
 

@@ -13,6 +13,8 @@ the gradient exchange is the Trainer's flat all-reduce; data comes from utils.da
 import argparse
 import logging
 import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before the first HIP call: see cwf/__init__.py (stream -> hardware-queue multiplexing)
 import random
 import sys
 import time

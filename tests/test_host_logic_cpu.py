@@ -193,3 +193,10 @@ def test_carry_link_routes_the_residual_gradient_and_sums_other_consumers(emul_b
     assert torch.allclose(x.grad.permute(0, 4, 1, 2, 3), xr.grad, rtol=1e-4, atol=1e-5)
     assert torch.allclose(w1.grad, w1r.grad, rtol=1e-4, atol=1e-5) and torch.allclose(w2.grad, w2r.grad, rtol=1e-4, atol=1e-5)
     assert y.data_ptr() == buf.data_ptr() and torch.equal(buf[..., :c], y.detach())
+
+
+def test_package_import_asks_for_eight_hardware_queues():
+    """cwf/__init__.py: GPU_MAX_HW_QUEUES defaults to 8 before the first HIP call (with the runtime's default 4 the data-parallel step's
+    streams share hardware queues and the launch plan's cross-stream waits serialise: 27.6 instead of 18.3 ms per step, tools/r3_comm.sh)."""
+    import cwf  # noqa: F401
+    assert os.environ.get("GPU_MAX_HW_QUEUES") is not None
