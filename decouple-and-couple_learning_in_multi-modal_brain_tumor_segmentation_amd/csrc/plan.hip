@@ -293,7 +293,10 @@ extern "C" int cwf_plan_create(void* graph_, void** out) {
         hipEvent_t ev;
         // stream 1 = the weight-gradient chain: the runtime's LOW priority (its own hardware-queue pool and the right scheduling hint
         // beside the data-gradient chain, see cwf.kernels.HipBackend.wgrad_stream); further streams: high
-        e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, c == 1 ? least : greatest);
+        static const char* sp = getenv("CWF_PLAN_SIDE_PRIO");          // A/B: "normal" / "high" for the weight-gradient stream (default low)
+        int side_prio = least;
+        if (sp && !strcmp(sp, "normal")) side_prio = (least + greatest) / 2; else if (sp && !strcmp(sp, "high")) side_prio = greatest;
+        e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, c == 1 ? side_prio : greatest);
         if (e != hipSuccess) { destroy(P); return (int)e; }
         P->owned.push_back(st);
         e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
