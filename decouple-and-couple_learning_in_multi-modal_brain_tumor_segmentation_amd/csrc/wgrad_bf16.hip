@@ -21,9 +21,10 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 // no CU with room and waits for a whole side kernel; fewer workgroups leave CUs to the main stream (an isolated launch is slower,
 // the step faster).  Round 2, launches from Python: 192 (99.3 -> 100.1 volumes/s).  Round 3, launch plan (the main stream never
 // waits for the host any more): 128 -- 64 / 96 / 128 / 160 / 192 / 256 give 91.3 / 99.9 / 104.8 / 103.7 / 103.1 / 102.6 volumes/s.
+// End of round 3 (LDS-DMA weight gradients; only their chain off the main stream): 128 / 160 / 192 / 256 give 110.0 / 110.4 / 110.0 / 108.9: 160.
 // CWF_SIDE_WGS overrides (multiple of 8).
 extern "C" int cwf_wgrad_nsplit(int op, int N, int Do, int Ho, int Wo, int Cin, int Cout);
-static int side_wgs() { static const int v = getenv("CWF_SIDE_WGS") ? atoi(getenv("CWF_SIDE_WGS")) : 128; return v; }
+static int side_wgs() { static const int v = getenv("CWF_SIDE_WGS") ? atoi(getenv("CWF_SIDE_WGS")) : 160; return v; }
 
 struct WgArgsB {
   ConvGeom g;
