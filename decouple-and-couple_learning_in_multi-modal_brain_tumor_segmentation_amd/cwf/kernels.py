@@ -132,6 +132,7 @@ class HipBackend:
         self._wg_tables = {}
         self.wgrad_async = False
         self._rng_lock = threading.Lock()      # the autograd engine may call in from its own thread
+        self._no_stem = bool(os.environ.get("CWF_NO_STEM_KERNEL"))      # A/B: the stem on conv16s (K slots 3/4 empty)
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -240,6 +241,13 @@ class HipBackend:
                 nbp = (nb_x.data_ptr(), nb_ldc, nb_scale.data_ptr(), nb_shift.data_ptr(), float(nb_slope))
             self._call("cwf_conv_mfma_bf16_in16", op, x16.data_ptr(), self.zero16(x.device).data_ptr(), wpk.data_ptr(), _p(bias),
                        y.data_ptr(), y_ldc, _p(residual), r_ldc, _p(stats), *nbp, n, di, hi, wi, self._stream())
+            return y
+        if (op == pk.CONV3_S1 and cin == 4 and cout == 16 and mode != "fp32" and fwd_op is None and in_scale is None and residual is None
+                and nb is None and torch.is_tensor(w_ref) and tuple(w_ref.shape) == (16, 4, 3, 3, 3) and w_ref.is_contiguous()
+                and w_ref.dtype == _f32 and do * ho * wo >= 32768 and not self._no_stem):
+            # the stem: K = 8 taps x 4 channels (conv_stem.hip), straight from the raw weight
+            self._call("cwf_conv_stem_bf16", 1 if mode == "bf16x3" else 0, x.data_ptr(), x_ldc, w_ref.data_ptr(), _p(bias), y.data_ptr(), y_ldc,
+                       _p(out_scale), _p(stats), n, di, hi, wi, self._stream())
             return y
         if mode == "fp32":
             self._call("cwf_conv_mfma", op, x.data_ptr(), x_ldc, wpk.data_ptr(), _p(bias), y.data_ptr(), y_ldc,

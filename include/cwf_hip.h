@@ -87,6 +87,12 @@ int cwf_wgrad_reduce_batched(const struct cwf_wgrad_reduce_desc* table, int nlay
 
 struct cwf_gather_desc { const float* src; float* dst; const int32_t* map; int64_t n; };
 
+/* The stem: y = (conv3x3x3(x; w) + bias) * out_scale for 4 -> 16 channels (InitConv + its always-on dropout3d, Unet_skipconnection.py:22-33)
+ * with K = 8 taps x 4 channels per MFMA step; x [N][D][H][W][4] fp32 (ldc x_ldc), w the RAW nn.Conv3d weight [16][4][3][3][3], y ldc y_ldc;
+ * out_scale [N][16] and stats [N][16][2] (sum, sum of squares of y) nullable.  x3: split-bf16 (3 MFMAs) / single bf16. */
+int cwf_conv_stem_bf16(int x3, const float* x, int x_ldc, const float* w, const float* bias, float* y, int y_ldc,
+                       const float* out_scale, double* stats, int N, int D, int H, int W, void* stream);
+
 /* Split-bf16 forms of K1 (same geometry, epilogues and argument meaning; activations and weights stay fp32 in HBM):
  * MFMA operands are bf16 on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.
  *   x3 != 0 ("bf16x3"): v = hi + lo per operand, products hi.hi + hi.lo + lo.hi  (~2^-16 relative per product, 3 MFMAs)

@@ -215,6 +215,31 @@ def test_dma_weight_gradient_32_channel_groups(hip, cin, cout, size, n):
     close(db_b, gb_ref, rtol=PREC_TOL["bf16"], what="dma bgrad vs oracle")
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("size,n", [((32, 32, 32), 2), ((34, 38, 50), 1), ((64, 64, 64), 2)])
+def test_stem_kernel_packs_eight_taps_times_four_channels(hip, size, n, prec):
+    """cwf_conv_stem_bf16 (K = 8 taps x 4 channels, raw weights) against the oracle and against the 16-channel-slot kernel it replaces
+    (same operand values, another summation order), with bias, dropout3d scale and output statistics; ragged tiles included."""
+    from cwf import functional as CF
+    d, h, w_ = size
+    x = rnd(n, d, h, w_, 4, seed=51)
+    w = rnd(16, 4, 3, 3, 3, seed=52, scale=1.0 / math.sqrt(4 * 27))
+    b = rnd(16, seed=53, scale=0.1)
+    osc = (rnd(n, 16, seed=54) > -0.5).float() * 1.25
+    spec = _packed(CF.ConvSpec(pk.CONV3_S1, 4, 16), w, prec)
+    xd, wd, bd, od = x.to(DEV), w.to(DEV).contiguous(), b.to(DEV), osc.to(DEV)
+    st_a, st_b = hip.new_stats(n, 16, DEV), hip.new_stats(n, 16, DEV)
+    y_a = hip.conv(pk.CONV3_S1, xd, spec.wpk16_f, bd, 16, out_scale=od, stats=st_a, prec=prec, w_ref=wd)           # stem kernel
+    y_b = hip.conv(pk.CONV3_S1, xd, spec.wpk16_f, bd, 16, out_scale=od, stats=st_b, prec=prec)                     # conv16s
+    st_ref = E.new_stats(n, 16, None)
+    y_ref = E.conv(pk.CONV3_S1, x, None, b, 16, None, None, 1.0, None, osc, st_ref, w_ref=w)
+    tol = PREC_TOL[prec]
+    close(y_a, y_ref, rtol=tol, what="stem vs oracle")
+    close(st_a, st_ref, rtol=max(1e-5, tol), what="stem stats vs oracle")
+    close(y_a, y_b.cpu(), rtol=2e-5 if prec == "bf16x3" else 2e-5, what="stem vs conv16s")
+    close(st_a, st_b.cpu(), rtol=2e-5, what="stem stats vs conv16s")
+
+
 def _bf16_rne(t):
     """round-to-nearest-even bf16 of an fp32 tensor (what v_cvt_pk_bf16_f32 does)"""
     return t.to(torch.bfloat16)
