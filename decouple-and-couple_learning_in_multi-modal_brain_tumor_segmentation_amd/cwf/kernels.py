@@ -249,6 +249,14 @@ class HipBackend:
             self._call("cwf_conv_stem_bf16", 1 if mode == "bf16x3" else 0, x.data_ptr(), x_ldc, w_ref.data_ptr(), _p(bias), y.data_ptr(), y_ldc,
                        _p(out_scale), _p(stats), n, di, hi, wi, self._stream())
             return y
+        if (op == pk.CONV3_S2 and cin == 16 and cout == 32 and mode != "fp32" and fwd_op is None and in_scale is None and residual is None
+                and out_scale is None and nb is None and torch.is_tensor(w_ref) and tuple(w_ref.shape) == (32, 16, 3, 3, 3) and w_ref.is_contiguous()
+                and w_ref.dtype == _f32 and do * ho * wo >= 32768 and not self._no_stem
+                and (do, ho, wo) == ((di + 1) // 2, (hi + 1) // 2, (wi + 1) // 2)):
+            # the first down-sampling layer: persistent prefetching kernel with parity-split halo rows (conv_s2.hip)
+            self._call("cwf_conv_s2c16_bf16", 1 if mode == "bf16x3" else 0, x.data_ptr(), x_ldc, w_ref.data_ptr(), _p(bias), y.data_ptr(), y_ldc,
+                       _p(stats), n, di, hi, wi, self._stream())
+            return y
         if mode == "fp32":
             self._call("cwf_conv_mfma", op, x.data_ptr(), x_ldc, wpk.data_ptr(), _p(bias), y.data_ptr(), y_ldc,
                        _p(in_scale), _p(in_shift), float(slope), _p(residual), r_ldc, _p(out_scale), _p(stats),

@@ -93,6 +93,12 @@ struct cwf_gather_desc { const float* src; float* dst; const int32_t* map; int64
 int cwf_conv_stem_bf16(int x3, const float* x, int x_ldc, const float* w, const float* bias, float* y, int y_ldc,
                        const float* out_scale, double* stats, int N, int D, int H, int W, void* stream);
 
+/* The first down-sampling layer: y = conv3x3x3 stride 2 (x; w) + bias for 16 -> 32 channels (EnDown1, Unet_skipconnection.py:60-68); x
+ * [N][Di][Hi][Wi][16] fp32 (ldc x_ldc), w the RAW nn.Conv3d weight [32][16][3][3][3], y [N][(Di+1)/2][(Hi+1)/2][(Wi+1)/2][32] (ldc y_ldc);
+ * stats [N][32][2] nullable. */
+int cwf_conv_s2c16_bf16(int x3, const float* x, int x_ldc, const float* w, const float* bias, float* y, int y_ldc, double* stats,
+                        int N, int Di, int Hi, int Wi, void* stream);
+
 /* Split-bf16 forms of K1 (same geometry, epilogues and argument meaning; activations and weights stay fp32 in HBM):
  * MFMA operands are bf16 on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.
  *   x3 != 0 ("bf16x3"): v = hi + lo per operand, products hi.hi + hi.lo + lo.hi  (~2^-16 relative per product, 3 MFMAs)

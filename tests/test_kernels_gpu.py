@@ -240,6 +240,31 @@ def test_stem_kernel_packs_eight_taps_times_four_channels(hip, size, n, prec):
     close(st_a, st_b.cpu(), rtol=2e-5, what="stem stats vs conv16s")
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("size,n", [((64, 64, 64), 2), ((34, 38, 70), 1), ((128, 128, 128), 1)])
+def test_first_downsampling_kernel(hip, size, n, prec):
+    """cwf_conv_s2c16_bf16 (3x3x3 stride 2, 16 -> 32, parity-split halo rows, raw weights) against the oracle and against the tap-table
+    kernel it replaces, with bias and output statistics; odd extents / ragged tiles included."""
+    from cwf import functional as CF
+    d, h, w_ = size
+    x = rnd(n, d, h, w_, 16, seed=61)
+    w = rnd(32, 16, 3, 3, 3, seed=62, scale=1.0 / math.sqrt(16 * 27))
+    b = rnd(32, seed=63, scale=0.1)
+    spec = _packed(CF.ConvSpec(pk.CONV3_S2, 16, 32), w, prec)
+    xd, wd, bd = x.to(DEV), w.to(DEV).contiguous(), b.to(DEV)
+    st_a, st_b = hip.new_stats(n, 32, DEV), hip.new_stats(n, 32, DEV)
+    y_a = hip.conv(pk.CONV3_S2, xd, spec.wpk16_f, bd, 32, stats=st_a, prec=prec, w_ref=wd)           # new kernel
+    y_b = hip.conv(pk.CONV3_S2, xd, spec.wpk16_f, bd, 32, stats=st_b, prec=prec)                     # tap-table kernel
+    tol = PREC_TOL[prec]
+    close(y_a, y_b.cpu(), rtol=2e-5, what="s2 kernel vs tap-table kernel")
+    close(st_a, st_b.cpu(), rtol=2e-5, what="s2 stats vs tap-table kernel")
+    if d * h * w_ <= 64 ** 3:
+        st_ref = E.new_stats(n, 32, None)
+        y_ref = E.conv(pk.CONV3_S2, x, None, b, 32, None, None, 1.0, None, None, st_ref, w_ref=w)
+        close(y_a, y_ref, rtol=tol, what="s2 vs oracle")
+        close(st_a, st_ref, rtol=max(1e-5, tol), what="s2 stats vs oracle")
+
+
 def _bf16_rne(t):
     """round-to-nearest-even bf16 of an fp32 tensor (what v_cvt_pk_bf16_f32 does)"""
     return t.to(torch.bfloat16)
