@@ -368,8 +368,10 @@ def test_batch_two_at_bench_shape_128(hip):
             logit = logits2[0:1].reshape(-1)[si].cpu().numpy()
             assert np.abs(logit - g["logits_sample"]).max() / np.abs(g["logits_sample"]).max() <= 1e-3
             one = m(x[1:2].to(DEV), None)
-            assert float((both[0][1:2] - one[0]).abs().max()) < 1e-5
-            assert float((both[2]["04"][1:2] - one[2]["04"]).abs().max()) < 1e-5
+            # (independent samples up to the summation order of the InstanceNorm statistics: the persistent kernels split their tile runs
+            # over the workgroups by the TOTAL tile count, so a sample's fp32 partial sums group differently at B = 1 and B = 2)
+            assert float((both[0][1:2] - one[0]).abs().max()) < 3e-5
+            assert float((both[2]["04"][1:2] - one[2]["04"]).abs().max()) < 3e-5
     finally:
         kernels.set_precision("fp32")
 

@@ -17,6 +17,7 @@ python tools/pmc_summary.py gpurun_out/r3f_pmc_dgrad16 conv16s_kernel >> gpurun_
 python tools/pmc_summary.py gpurun_out/r3f_pmc_apply16 in_bwd_apply_kernel >> gpurun_out/r3f_pmc_summary.txt
 bash tools/gpu_census.sh r3f
 python tools/layer_table.py > gpurun_out/r3f_layer_table.txt 2>/dev/null
+bash tools/r3_tl_stats.sh r3f_tl > /dev/null
 R=$GRAFT_REPO_ROOT
 cd /tmp
 rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/r3f_micro -o m -- python $R/tools/conv16_micro.py bf16x3 20 conv > $R/gpurun_out/r3f_micro.log 2>&1
