@@ -23,6 +23,9 @@ struct ConvArgsB {
   const uint4* wpk_g[3]; const float* bias_g[3];
   // conv16s, IN16 instantiation: the input as a bf16 image (16-byte granules, two per voxel) and the 16-byte zero page of its loaders
   const uint4* x16; const uint4* zero16;
+  // pointwise stream kernel (1x1x1 forward): the output also as a bf16 image [N][V][Cout] (the operand image of a consuming layer's weight
+  // gradient, see cwf_conv_mfma_bf16_y16): one extra 8-byte store per lane
+  unsigned short* y16;
 };
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));

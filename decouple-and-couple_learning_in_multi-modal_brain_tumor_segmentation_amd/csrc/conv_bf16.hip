@@ -1503,6 +1503,8 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(const ConvArgsB a, const P
             f32x4 v = acc[t];
             if (HAS_RES) v += rv[HAS_RES ? k : 0][t];
             *reinterpret_cast<f32x4*>(yp + t * 16) = v;
+            if (NCLS == 1 && a.y16)
+              *reinterpret_cast<uint2*>(a.y16 + ((int64_t)n * g.Do * g.Ho * g.Wo + ovox) * g.Cout + cb) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
             if (HAS_NB) {
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
@@ -1719,7 +1721,7 @@ static int conv_bf16_impl(int op, int x3, const float* x, int x_ldc, const void*
                           const float* residual, int r_ldc, const float* out_scale, double* stats,
                           const float* nb_x, int nb_ldc, const float* nb_scale, const float* nb_shift, float nb_slope,
                           int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, void* stream,
-                          const void* x16, const void* zero16);
+                          const void* x16, const void* zero16, void* y16 = nullptr);
 
 extern "C" int cwf_conv_mfma_bf16_nb(int op, int x3, const float* x, int x_ldc, const void* wpk16, const float* bias,
                                      float* y, int y_ldc, const float* in_scale, const float* in_shift, float in_slope,
@@ -1728,6 +1730,18 @@ extern "C" int cwf_conv_mfma_bf16_nb(int op, int x3, const float* x, int x_ldc, 
                                      int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, void* stream) {
   return conv_bf16_impl(op, x3, x, x_ldc, wpk16, bias, y, y_ldc, in_scale, in_shift, in_slope, residual, r_ldc, out_scale, stats,
                         nb_x, nb_ldc, nb_scale, nb_shift, nb_slope, N, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, stream, nullptr, nullptr);
+}
+
+// cwf_conv_mfma_bf16 for a 1x1x1 conv that also writes its output as a bf16 image y16 [N][Do*Ho*Wo][Cout] (DeUp_Cat.conv3, cls_wise_former.py:
+// 716-729: its output is the un-normalised input of the next block's first conv, whose weight gradient reads that image).  CWF_E_BADARG
+// if the layer is not one the pointwise stream kernel takes (the caller then converts with cwf_to_bf16).
+extern "C" int cwf_conv_mfma_bf16_y16(int op, int x3, const float* x, int x_ldc, const void* wpk16, const float* bias,
+                                      float* y, int y_ldc, void* y16, const float* in_scale, const float* in_shift, float in_slope,
+                                      const float* residual, int r_ldc, double* stats,
+                                      int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, void* stream) {
+  if (!y16) return CWF_E_BADARG;
+  return conv_bf16_impl(op, x3, x, x_ldc, wpk16, bias, y, y_ldc, in_scale, in_shift, in_slope, residual, r_ldc, nullptr, stats,
+                        nullptr, 0, nullptr, nullptr, 1.f, N, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, stream, nullptr, nullptr, y16);
 }
 
 // The same conv with its INPUT given as a bf16 image x16 [N][Di][Hi][Wi][16] (single-bf16 operand launches of the 3x3x3 stride-1
@@ -1748,7 +1762,7 @@ static int conv_bf16_impl(int op, int x3, const float* x, int x_ldc, const void*
                           const float* residual, int r_ldc, const float* out_scale, double* stats,
                           const float* nb_x, int nb_ldc, const float* nb_scale, const float* nb_shift, float nb_slope,
                           int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, void* stream,
-                          const void* x16, const void* zero16) {
+                          const void* x16, const void* zero16, void* y16) {
   if (!x || !wpk16 || !y || N <= 0 || Cin <= 0 || Cout <= 0) return CWF_E_BADARG;
   if (nb_x && (!stats || !nb_scale || !nb_shift || nb_ldc < Cout)) return CWF_E_BADARG;
   if ((Cin & 3) || (x_ldc & 3) || x_ldc < Cin || y_ldc < Cout) return CWF_E_ALIGN;
@@ -1772,6 +1786,7 @@ static int conv_bf16_impl(int op, int x3, const float* x, int x_ldc, const void*
   a.diag = nullptr; a.diag_mode = 0;
   a.groups = 0; a.x_goff = 0; a.y_goff = 0;
   a.x16 = reinterpret_cast<const uint4*>(x16); a.zero16 = reinterpret_cast<const uint4*>(zero16);
+  a.y16 = reinterpret_cast<unsigned short*>(y16);
   for (int q = 0; q < 3; ++q) { a.wpk_g[q] = nullptr; a.bias_g[q] = nullptr; }
   hipStream_t st = cwf_stream(stream);
   if (x16) {                                           // (cwf_conv_mfma_bf16_in16 has checked the layer)
@@ -1785,8 +1800,10 @@ static int conv_bf16_impl(int op, int x3, const float* x, int x_ldc, const void*
   {
     int ks, nt;
     if (pw_eligible(op, a, &ks, &nt)) {                   // 1x1x1 / ConvTranspose streams: no LDS staging (pw_conv_kernel)
+      if (y16 && (op != CWF_CONV1 || (Cout & 3) || ((uintptr_t)y16 & 7))) return CWF_E_BADARG;
       return x3 ? dispatch_pw<true>(op, a, st, ks, nt) : dispatch_pw<false>(op, a, st, ks, nt);
     }
+    if (y16) return CWF_E_BADARG;                        // the bf16 side output is the pointwise stream kernel's
   }
   {
     int rcw = 0;                                           // 32 / 64 / 128-channel 3x3x3 layers: weight-stationary kernel (conv_ws.hip)
@@ -1834,7 +1851,7 @@ extern "C" int cwf_conv_mfma_bf16_grouped(int op, int x3, const float* x, int x_
   a.nb_x = nullptr; a.nb_ldc = 0; a.nb_scale = nullptr; a.nb_shift = nullptr; a.nb_slope = 1.f;
   a.diag = nullptr; a.diag_mode = 0;
   a.groups = groups; a.x_goff = x_goff; a.y_goff = y_goff;
-  a.x16 = nullptr; a.zero16 = nullptr;
+  a.x16 = nullptr; a.zero16 = nullptr; a.y16 = nullptr;
   for (int q = 0; q < 3; ++q) {
     a.wpk_g[q] = q < groups ? reinterpret_cast<const uint4*>(wpk16[q]) : nullptr;
     a.bias_g[q] = (q < groups && bias) ? bias[q] : nullptr;

@@ -22,6 +22,7 @@ SIGNATURES = {
     "cwf_conv_mfma_bf16": [I, I, P, I, P, P, P, I, P, P, F, P, I, P, P, I, I, I, I, I, I, I, I, I, P],
     "cwf_conv_mfma_bf16_nb": [I, I, P, I, P, P, P, I, P, P, F, P, I, P, P, P, I, P, P, F, I, I, I, I, I, I, I, I, I, P],
     "cwf_conv_s2c16_bf16": [I, P, I, P, P, P, I, P, I, I, I, I, P],
+    "cwf_conv_mfma_bf16_y16": [I, I, P, I, P, P, P, I, P, P, P, F, P, I, P, I, I, I, I, I, I, I, I, I, P],
     "cwf_conv_stem_bf16": [I, P, I, P, P, P, I, P, P, I, I, I, I, P],
     "cwf_wgrad_mfma_bf16": [I, I, P, I, P, P, F, P, I, P, I, I, I, I, I, I, I, I, I, P, P],
     "cwf_gather_split_bf16": [P, I, L, P],

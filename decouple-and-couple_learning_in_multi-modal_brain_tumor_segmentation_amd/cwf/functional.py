@@ -163,7 +163,7 @@ class WeightPacker:
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, spec, in_scale, in_shift, slope, residual, out_scale, want_stats, carry, x_link, out=None, res_link=None,
-                carry_link=None):
+                carry_link=None, y16=None):
         K = backend()
         ctx.set_materialize_grads(False)     # (autograd would zero-FILL a gradient for each of the (scale, shift) outputs: 2 launches per conv)
         ctx.x_link = x_link
@@ -178,8 +178,9 @@ class _ConvFn(torch.autograd.Function):
         spec.uses += 1
         stats = K.new_stats(n, spec.cout, x.device) if want_stats else None
         # out: a channel slice of a wider buffer (the conv writes its half of a concatenation in place: no copy launch)
+        kwy = dict(y16=y16) if y16 is not None else {}       # (a preallocated bf16 image of the output, written by the same launch)
         y = K.conv(spec.op, x, spec.packed(False), b, spec.cout, in_scale, in_shift, slope, residual, out_scale, stats,
-                   out=out, w_ref=w, out_channels_alloc=spec.cout_alloc)
+                   out=out, w_ref=w, out_channels_alloc=spec.cout_alloc, **kwy)
         ctx.spec, ctx.slope = spec, slope
         ctx.bias_ref = b
         ctx.has_res = residual is not None
@@ -218,7 +219,7 @@ class _ConvFn(torch.autograd.Function):
                 dcarry = gq if dcarry is None else K.add(dcarry, gq)
             ctx.carry_link.grads = []
         if dy is None:                       # y itself unused downstream: only the carried alias has a gradient
-            return (dcarry,) + (None,) * 14
+            return (dcarry,) + (None,) * 15
         x, w, in_scale, in_shift, out_scale = ctx.saved_tensors
         spec = ctx.spec
         dys = None
@@ -338,7 +339,7 @@ class _ConvFn(torch.autograd.Function):
             dw = dwf.view(w.shape)
             if db is None:      # ConvTranspose: bias gradient spans the 8 parity classes
                 db = K.stats_channel_sum(K.in_stats(dy), torch.empty(spec.cout, dtype=torch.float32, device=dy.device))
-        return dx, dw, db, None, None, None, None, dres, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, dres, None, None, None, None, None, None, None, None
 
 
 class _FusedConvFn(torch.autograd.Function):
@@ -429,7 +430,7 @@ class CarryLink:
         self.grads = []
 
 
-def conv(x, w, b, spec, in_norm=None, slope=1.0, residual=None, out_scale=None, want_stats=False, carry=False, out=None):
+def conv(x, w, b, spec, in_norm=None, slope=1.0, residual=None, out_scale=None, want_stats=False, carry=False, out=None, emit16=False):
     """y = conv(act(IN(x)))(+bias)(+residual)(*out_scale).  in_norm = (scale, shift) of x or None.
     Returns (y, (scale_y, shift_y) or None), with carry=True (y, stats, x_alias): use x_alias for every further use of x
     (see _ConvFn.forward).  out: write y into this [N,D,H,W,cout] view (a channel slice of a concatenation buffer, see cat_into)."""
@@ -443,7 +444,18 @@ def conv(x, w, b, spec, in_norm=None, slope=1.0, residual=None, out_scale=None, 
             link = None
     res_link = getattr(residual, "_cwf_carry", None) if residual is not None else None
     carry_link = CarryLink() if (carry and torch.is_grad_enabled()) else None
-    y, s1, s2, xc = _ConvFn.apply(x, w, b, spec, sc, sh, float(slope), residual, out_scale, want_stats, carry, link, out, res_link, carry_link)
+    # emit16: the output is the un-normalised input of a layer whose weight gradient reads bf16 operand images (a 1x1x1 conv in front of a
+    # block's first conv): the same launch writes bf16(y)
+    y16 = None
+    ok16_ = getattr(backend(), "bf16_operands_ok", None)
+    if emit16 and ok16_ is not None and torch.is_grad_enabled() and "xa" in getattr(backend(), "APPLY_EMITS", ()) and out is None and out_scale is None \
+            and not _os.environ.get("CWF_NO_PW_Y16"):
+        n_, d_, h_, w_ = x.shape[0], *pk.out_dims(spec.op, x.shape[1], x.shape[2], x.shape[3])
+        if ok16_(pk.CONV3_S1, spec.cout, spec.cout, d_ * h_ * w_) and (spec.cout_alloc or spec.cout) == spec.cout:
+            y16 = torch.empty((n_, d_, h_, w_, spec.cout), dtype=torch.bfloat16, device=x.device)
+    y, s1, s2, xc = _ConvFn.apply(x, w, b, spec, sc, sh, float(slope), residual, out_scale, want_stats, carry, link, out, res_link, carry_link, y16)
+    if y16 is not None:
+        y._cwf16x = y16
     if carry_link is not None and xc is not None:
         xc._cwf_carry = carry_link
     if xc is not None and getattr(x, "_cwf_catbuf", None) is not None:

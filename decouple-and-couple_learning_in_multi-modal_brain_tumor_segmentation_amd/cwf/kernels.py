@@ -207,7 +207,7 @@ class HipBackend:
 
     # ------------------------------------------------------------------ K1
     def conv(self, op, x, wpk, bias, cout, in_scale=None, in_shift=None, slope=1.0, residual=None, out_scale=None,
-             stats=None, out=None, w_ref=None, out_channels_alloc=None, fwd_op=None, prec=None, nb=None, bias_ref=None, x16=None):
+             stats=None, out=None, w_ref=None, out_channels_alloc=None, fwd_op=None, prec=None, nb=None, bias_ref=None, x16=None, y16=None):
         """Returns the output buffer.  With out_channels_alloc > cout the buffer has zero-filled padding channels
         (2-channel heads live in 4-channel tensors so that every later kernel sees 16-byte voxel rows).
         w_ref / bias_ref (the original parameters; tuples for a fused layer) and fwd_op are not read here: the kernels take the
@@ -241,6 +241,19 @@ class HipBackend:
                 nbp = (nb_x.data_ptr(), nb_ldc, nb_scale.data_ptr(), nb_shift.data_ptr(), float(nb_slope))
             self._call("cwf_conv_mfma_bf16_in16", op, x16.data_ptr(), self.zero16(x.device).data_ptr(), wpk.data_ptr(), _p(bias),
                        y.data_ptr(), y_ldc, _p(residual), r_ldc, _p(stats), *nbp, n, di, hi, wi, self._stream())
+            return y
+        if y16 is not None:
+            # 1x1x1 forward that also leaves its output as a bf16 image (y16 [N,D,H,W,cout] bfloat16): the pointwise stream kernel's side
+            # output; any other layer converts afterwards
+            assert x16 is None and nb is None and out_scale is None and y16.dtype == torch.bfloat16 and y16.is_contiguous()
+            rc = 1
+            if mode != "fp32" and op == pk.CONV1:
+                rc = self.lib.cwf_conv_mfma_bf16_y16(op, 1 if mode == "bf16x3" else 0, x.data_ptr(), x_ldc, wpk.data_ptr(), _p(bias), y.data_ptr(), y_ldc,
+                                                     y16.data_ptr(), _p(in_scale), _p(in_shift), float(slope), _p(residual), r_ldc, _p(stats),
+                                                     n, di, hi, wi, cin, do, ho, wo, cout, self._stream())
+            if rc != 0:
+                self.conv(op, x, wpk, bias, cout, in_scale, in_shift, slope, residual, None, stats, out=y, w_ref=w_ref, prec=prec, bias_ref=bias_ref)
+                self.to_bf16(y if y.shape[-1] == cout else y[..., :cout], out=y16)      # (no copy node: a captured step stays plan-able)
             return y
         if (op == pk.CONV3_S1 and cin == 4 and cout == 16 and mode != "fp32" and fwd_op is None and in_scale is None and residual is None
                 and nb is None and torch.is_tensor(w_ref) and tuple(w_ref.shape) == (16, 4, 3, 3, 3) and w_ref.is_contiguous()
@@ -349,11 +362,12 @@ class HipBackend:
                    sums.data_ptr(), _p(dx_add), a_ldc, dx.data_ptr() if need_f32 else 0, c, _p(dx16), _p(xa16), n, d * h * w, c, self._stream())
         return dx, dx16, xa16
 
-    def to_bf16(self, x, scale=None, shift=None, slope=1.0):
+    def to_bf16(self, x, scale=None, shift=None, slope=1.0, out=None):
         """bf16(act(x*scale+shift)) (scale None: bf16(x)) as a [N,D,H,W,C] bfloat16 tensor -- a stream pass, for operands no producer emitted."""
         x, x_ldc = cl(x)
         n, d, h, w, c = x.shape
-        y = torch.empty((n, d, h, w, c), dtype=torch.bfloat16, device=x.device)
+        y = out if out is not None else torch.empty((n, d, h, w, c), dtype=torch.bfloat16, device=x.device)
+        assert y.dtype == torch.bfloat16 and y.is_contiguous() and tuple(y.shape) == (n, d, h, w, c)
         self._call("cwf_to_bf16", x.data_ptr(), x_ldc, _p(scale), _p(shift), float(slope), y.data_ptr(), n, d * h * w, c, self._stream())
         return y
 

@@ -205,9 +205,13 @@ class Trainer:
                 self._plan = plan
                 self.plan_info = dict(zip(("nodes", "kernels", "markers", "streams", "events", "on_stream0", "on_stream1", "on_streams2plus"), list(info)))
             else:
-                # a node kind the launch list cannot express: replay the graph the ordinary way (collectives then follow the replay)
-                self.plan_info = {"error": int(rc), "detail": (K.lib.cwf_plan_last_error() or b"").decode()}
-                self.overlap_comm = False
+                # a node kind the launch list cannot express (e.g. a copy node): go on EAGERLY -- the step is GPU-bound, eager launches
+                # run it as fast as the plan (they only cost more host time), while hipGraphLaunch of the same capture is 30 % slower
+                self.plan_info = {"error": int(rc), "detail": (K.lib.cwf_plan_last_error() or b"").decode(), "fallback": "eager"}
+                self._graph = None
+                self._static = None
+                self.use_graph = False
+                self.graph_mode = None
 
     def _run_plan(self):
         import ctypes

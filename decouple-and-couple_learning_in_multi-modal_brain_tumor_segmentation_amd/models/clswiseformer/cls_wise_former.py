@@ -253,7 +253,7 @@ class DeUp_Cat(nn.Module):
             buf = CF.cat_buffer(prev, self.conv2.spec.cout)
         hi = buf[..., prev.shape[-1]:] if buf.data_ptr() != prev.data_ptr() else CF.alias_channels(buf, prev.shape[-1], buf.shape[-1])
         u, _ = self.conv2(t, out=hi)                              # the transposed conv writes its half of the concatenation in place
-        y, _ = self.conv3(CF.cat_into(prev, u, buf))
+        y, _ = self.conv3(CF.cat_into(prev, u, buf), emit16=True)    # (its output is the next block's un-normalised conv input)
         return y
 
 

@@ -26,8 +26,8 @@ class HipConv(nn.Module):
             op = pk.CONV3_S2 if stride == 2 else pk.CONV3_S1
         self.spec = CF.ConvSpec(op, cin, cout)
 
-    def forward(self, x, in_norm=None, slope=1.0, residual=None, out_scale=None, want_stats=False, carry=False, out=None):
-        return CF.conv(x, self.weight, self.bias, self.spec, in_norm, slope, residual, out_scale, want_stats, carry, out)
+    def forward(self, x, in_norm=None, slope=1.0, residual=None, out_scale=None, want_stats=False, carry=False, out=None, emit16=False):
+        return CF.conv(x, self.weight, self.bias, self.spec, in_norm, slope, residual, out_scale, want_stats, carry, out, emit16)
 
 
 def collect_convs(module, packer, skip=()):

@@ -181,6 +181,13 @@ int cwf_norm_act_add_ex(const float* x, int x_ldc, const float* scale, const flo
 /* y16 [N*V][C] bf16 = bf16(act(x*scale+shift))  (scale == NULL: bf16(x)) */
 int cwf_to_bf16(const float* x, int x_ldc, const float* scale, const float* shift, float slope, void* y16,
                 int N, int64_t V, int C, void* stream);
+/* cwf_conv_mfma_bf16 for a 1x1x1 conv (CWF_CONV1, Cout a multiple of 4) that ALSO writes its output as a bf16 image y16 [N][Do*Ho*Wo][Cout]
+ * (DeUp_Cat.conv3, cls_wise_former.py:716-729: the un-normalised input of the next block's first conv, whose weight gradient reads that
+ * image).  CWF_E_BADARG if the layer is not one the pointwise stream kernel takes. */
+int cwf_conv_mfma_bf16_y16(int op, int x3, const float* x, int x_ldc, const void* wpk16, const float* bias,
+                           float* y, int y_ldc, void* y16, const float* in_scale, const float* in_shift, float in_slope,
+                           const float* residual, int r_ldc, double* stats,
+                           int N, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, void* stream);
 /* cwf_conv_mfma_bf16_nb (single-bf16 operand products) for a 3x3x3 stride-1 16 -> 16 layer of >= 32768 voxels whose INPUT exists as a
  * bf16 image x16 [N][D][H][W][16] -- the data gradient of EnBlock1 / EnBlock1_1 / DeBlock2 / DeBlock2_1 reading the bf16 image of dy that
  * cwf_in_bwd_apply_ex wrote (the data half of aten::convolution_backward, Unet_skipconnection.py:36-57).  zero16: 16 zero bytes. */

@@ -265,6 +265,21 @@ def test_first_downsampling_kernel(hip, size, n, prec):
         close(st_a, st_ref, rtol=max(1e-5, tol), what="s2 stats vs oracle")
 
 
+@pytest.mark.parametrize("cin,cout,size,n", [(32, 16, (32, 32, 32), 2), (64, 32, (16, 16, 16), 1), (128, 64, (8, 8, 8), 2), (16, 4, (8, 8, 16), 1)])
+def test_pointwise_conv_writes_its_bf16_image(hip, cin, cout, size, n):
+    """conv(..., y16=): the 1x1x1 stream kernel leaves bf16(y) beside y in the same launch (other layers: conversion afterwards)."""
+    from cwf import functional as CF
+    d, h, w_ = size
+    x = rnd(n, d, h, w_, cin, seed=71).to(DEV)
+    w = rnd(cout, cin, 1, 1, 1, seed=72, scale=1.0 / math.sqrt(cin))
+    b = rnd(cout, seed=73, scale=0.1).to(DEV)
+    spec = _packed(CF.ConvSpec(pk.CONV1, cin, cout), w, "bf16x3")
+    y_ref = hip.conv(pk.CONV1, x, spec.wpk16_f, b, cout, prec="bf16x3")
+    y16 = torch.empty((n, d, h, w_, cout), dtype=torch.bfloat16, device=DEV)
+    y = hip.conv(pk.CONV1, x, spec.wpk16_f, b, cout, prec="bf16x3", y16=y16)
+    assert torch.equal(y, y_ref) and torch.equal(y16, y_ref.to(torch.bfloat16))
+
+
 def _bf16_rne(t):
     """round-to-nearest-even bf16 of an fp32 tensor (what v_cvt_pk_bf16_f32 does)"""
     return t.to(torch.bfloat16)
