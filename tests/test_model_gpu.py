@@ -445,6 +445,25 @@ def test_graph_replay_matches_eager_step(hip, mode):
         kernels.set_precision("fp32")
 
 
+def test_unplannable_capture_falls_back_to_eager_steps(hip, monkeypatch):
+    """A capture the launch list cannot express (here: cwf_plan_create made to refuse) must not leave the Trainer on hipGraph replay
+    (30 % slower than eager launches on this runtime): it goes on eagerly, and the steps still train."""
+    from cwf import kernels
+    from cwf.trainer import Trainer
+    kernels.set_precision("bf16x3", wgrad="bf16", dgrad="bf16")
+    try:
+        x, t, e = syn.synthetic_batch([0], (64, 64, 64))
+        x, t, e = x.to(DEV), t.to(DEV), e.to(DEV)
+        tr = Trainer(_model().train(), use_graph="plan", graph_warmup=1)
+        K = kernels.backend()
+        monkeypatch.setattr(K.lib, "cwf_plan_create", lambda graph, out: -2)
+        losses = [float(tr.step(x, t, e, 0)[0]) for _ in range(4)]
+        assert tr._plan is None and tr._graph is None and not tr.use_graph and tr.plan_info.get("fallback") == "eager", tr.plan_info
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    finally:
+        kernels.set_precision("fp32")
+
+
 def test_gradient_sink_equals_plain_autograd(hip):
     """Trainer path (gradients written by the backward kernels into the flat buffer: batched split-K reduce per backward phase,
     coupler Functions writing their weight-set gradients in place, side-stream weight gradients) == plain `loss.backward()` of the
