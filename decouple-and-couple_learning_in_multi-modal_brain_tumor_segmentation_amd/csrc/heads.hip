@@ -260,9 +260,11 @@ __device__ __forceinline__ void hl_build_rows(float* P, const HeadLossArgs& a, i
 __device__ __forceinline__ void hl_prob(const float* Prow, int W, int w0, int w1, float lw, float* p) {
   float v0 = (1.f - lw) * Prow[w0 * 2] + lw * Prow[w1 * 2];
   float v1 = (1.f - lw) * Prow[w0 * 2 + 1] + lw * Prow[w1 * 2 + 1];
+  // (hardware exp2 / rcp: the fused head -> loss kernels are VALU-bound on 25 M of these per step; the full-precision expf / divide
+  // sequences cost ~4x the instructions for a difference of ~1e-7 relative, far inside the 1e-4 loss tolerance)
   const float mx = fmaxf(v0, v1);
-  v0 = expf(v0 - mx); v1 = expf(v1 - mx);
-  const float r = 1.f / (v0 + v1);
+  v0 = __expf(v0 - mx); v1 = __expf(v1 - mx);
+  const float r = __frcp_rn(v0 + v1);
   p[0] = v0 * r; p[1] = v1 * r;
 }
 
@@ -301,11 +303,12 @@ __global__ __launch_bounds__(256) void head_loss_sums_kernel(const HeadLossArgs 
       float p[2];
       hl_prob(P + (rr * a.nm + m) * a.W * 2, a.W, w0, w1, lw, p);
       const int cls = (int)((a.posmask[m] >> (lab & 31)) & 1u);
+      const float lp = __logf(fminf(fmaxf(cls ? p[1] : p[0], 0.005f), 1.0f));      // one logarithm: the true class's
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const float tt = (cls == c) ? 1.f : 0.f;
         acc[m][c][0] += p[c] * tt; acc[m][c][1] += p[c]; acc[m][c][2] += tt;
-        acc[m][c][3] += tt * logf(fminf(fmaxf(p[c], 0.005f), 1.0f));
+        acc[m][c][3] += tt * lp;
       }
     }
   }
